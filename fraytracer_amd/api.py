@@ -1,0 +1,450 @@
+"""Host-side mirror of FrayTracer's scene-composition API (the reference is F#; no .NET toolchain
+exists in the build image, so the host layer above the C ABI is written in Python — INTEGRATION.md
+shows the F# binding a maintainer would add).
+
+Names, argument order and behaviour follow the reference modules:
+
+    SdfForm.Primitive.sphere/capsule/torus/triangle   src/FrayTracer/SdfForm.fs:117-268
+    SdfForm.union/subtract/intersect/unionSmooth      src/FrayTracer/SdfForm.fs:14-91
+    SdfMaterial.createSolid                           src/FrayTracer/SdfMaterial.fs:4-7
+    SdfObject.create/union/subtract/intersect         src/FrayTracer/SdfObject.fs:6-64
+    SdfLight.directional/point                        src/FrayTracer/SdfLight.fs:6-42
+    SdfScene (record) / SdfScene.trace                src/FrayTracer/Types.fs:74-79, SdfScene.fs:7-28
+    Lens.create / Camera.lookAt                       src/FrayTracer/Camera.fs:11-42
+    ImageSize / Image.render                          src/FrayTracer/Image.fs:8-35
+
+Scene values are immutable descriptions (the reference's goal "immutable scenes", README.md:8).
+They are realised through libfraytracer_hip's constructor twins the first time they are rendered
+on a device.  The same descriptions can be realised on any object offering the small backend
+protocol below (tests realise them on the CPU oracle to compare results).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, FrayTracerError
+
+
+def _v3(v):
+    x, y, z = (float(np.float32(c)) for c in v)
+    return (x, y, z)
+
+
+class FColor(tuple):
+    """FColor.fs:8-33 — an RGB triple of float32."""
+
+    @staticmethod
+    def ofRGB(r, g, b):
+        return FColor(_v3((r, g, b)))
+
+
+# --------------------------------------------------------------------------------------------------
+# descriptions
+# --------------------------------------------------------------------------------------------------
+class _Desc:
+    __slots__ = ("kind", "args", "kids", "__weakref__")
+
+    def __init__(self, kind, args=(), kids=()):
+        object.__setattr__(self, "kind", kind)
+        object.__setattr__(self, "args", tuple(args))
+        object.__setattr__(self, "kids", tuple(kids))
+
+    def __setattr__(self, *_):
+        raise AttributeError("scene descriptions are immutable")
+
+    def __repr__(self):
+        return f"<{type(self).__name__} {self.kind} kids={len(self.kids)}>"
+
+
+class Form(_Desc):
+    pass
+
+
+class Material(_Desc):
+    pass
+
+
+class Object(_Desc):
+    pass
+
+
+class Light(_Desc):
+    pass
+
+
+class SdfForm:
+    class Primitive:
+        @staticmethod
+        def sphere(Center, Radius):
+            return Form("sphere", (_v3(Center), float(np.float32(Radius))))
+
+        @staticmethod
+        def capsule(From, To, Radius):
+            return Form("capsule", (_v3(From), _v3(To), float(np.float32(Radius))))
+
+        @staticmethod
+        def torus(Center, Normal, MajorRadius, MinorRadius):
+            return Form("torus", (_v3(Center), _v3(Normal), float(np.float32(MajorRadius)), float(np.float32(MinorRadius))))
+
+        @staticmethod
+        def triangle(V1, V2, V3, Radius):
+            return Form("triangle", (_v3(V1), _v3(V2), _v3(V3), float(np.float32(Radius))))
+
+        @staticmethod
+        def box(Center, HalfExtent):
+            """EXTENSION — not in the reference (BASELINE.json config 2 asks for boxes)."""
+            return Form("box", (_v3(Center), _v3(HalfExtent)))
+
+    @staticmethod
+    def union(forms):
+        forms = list(forms)
+        if not forms:
+            raise ValueError("No SdfObjects given.")            # SdfForm.fs:16
+        return forms[0] if len(forms) == 1 else Form("union", (), forms)
+
+    @staticmethod
+    def subtract(a, b):
+        return Form("subtract", (), (a, b))
+
+    @staticmethod
+    def intersect(forms):
+        forms = list(forms)
+        if not forms:
+            raise ValueError("No SdfObjects given.")            # SdfForm.fs:53
+        return forms[0] if len(forms) == 1 else Form("intersect", (), forms)
+
+    @staticmethod
+    def unionSmooth(strength, forms):
+        forms = list(forms)
+        if not forms:
+            raise ValueError("blub")                            # SdfForm.fs:71
+        return forms[0] if len(forms) == 1 else Form("unionSmooth", (float(np.float32(strength)),), forms)
+
+
+class SdfMaterial:
+    @staticmethod
+    def createSolid(color):
+        return Material("solid", (_v3(color),))
+
+
+class SdfObject:
+    @staticmethod
+    def create(material, form):
+        return Object("create", (), (material, form))
+
+    @staticmethod
+    def union(objects):
+        objects = list(objects)
+        if not objects:
+            raise ValueError("No SdfObjects given.")            # SdfObject.fs:14
+        return objects[0] if len(objects) == 1 else Object("union", (), objects)
+
+    @staticmethod
+    def subtract(object, form):
+        return Object("subtract", (), (object, form))
+
+    @staticmethod
+    def intersect(object, forms):
+        return Object("intersect", (), (object,) + tuple(forms))
+
+
+class SdfLight:
+    @staticmethod
+    def directional(direction, color):
+        return Light("directional", (_v3(direction), _v3(color)))
+
+    @staticmethod
+    def point(position, color):
+        return Light("point", (_v3(position), _v3(color)))
+
+
+class SdfScene:
+    """Types.fs:74-79 record {Object; BackgroundColor; Lights}."""
+
+    def __init__(self, Object, BackgroundColor, Lights=()):
+        self.Object = Object
+        self.BackgroundColor = _v3(BackgroundColor)
+        self.Lights = tuple(Lights)
+        self._realised = {}
+        self._lock = threading.Lock()
+
+    @staticmethod
+    def trace(scene, device=None):
+        """SdfScene.trace scene : Ray -> FColor (SdfScene.fs:7-8), evaluated on the GPU."""
+        return SceneTrace(scene, device)
+
+
+def realise(node, backend, memo=None):
+    """Build `node` on a backend (libfraytracer_hip context or the test oracle); returns its handle."""
+    memo = {} if memo is None else memo
+    key = id(node)
+    if key in memo:
+        return memo[key]
+    k = node.kind
+    kids = [realise(c, backend, memo) for c in node.kids]
+    if isinstance(node, Form):
+        if k == "sphere": h = backend.sphere(*node.args)
+        elif k == "capsule": h = backend.capsule(*node.args)
+        elif k == "torus": h = backend.torus(*node.args)
+        elif k == "triangle": h = backend.triangle(*node.args)
+        elif k == "box": h = backend.box(*node.args)
+        elif k == "union": h = backend.form_union(kids)
+        elif k == "subtract": h = backend.form_subtract(kids[0], kids[1])
+        elif k == "intersect": h = backend.form_intersect(kids)
+        elif k == "unionSmooth": h = backend.form_union_smooth(node.args[0], kids)
+        else: raise ValueError(k)
+    elif isinstance(node, Material):
+        h = backend.material_solid(node.args[0])
+    elif isinstance(node, Object):
+        if k == "create": h = backend.object_create(kids[0], kids[1])
+        elif k == "union": h = backend.object_union(kids)
+        elif k == "subtract": h = backend.object_subtract(kids[0], kids[1])
+        elif k == "intersect": h = backend.object_intersect(kids[0], kids[1:])
+        else: raise ValueError(k)
+    elif isinstance(node, Light):
+        h = backend.light_directional(*node.args) if k == "directional" else backend.light_point(*node.args)
+    else:
+        raise TypeError(type(node))
+    memo[key] = h
+    return h
+
+
+# --------------------------------------------------------------------------------------------------
+# libfraytracer_hip backend
+# --------------------------------------------------------------------------------------------------
+def _f3(v):
+    return (C.c_float * 3)(*v)
+
+
+def _handles(hs):
+    return (C.c_int32 * len(hs))(*hs), len(hs)
+
+
+def _vec(v):
+    return _lib.Vec3(*v)
+
+
+class Device:
+    """One ft_ctx: a GPU (index >= 0) or a host-only context (index -1: construction and
+    introspection only — rendering raises, there is no CPU fallback)."""
+
+    _default = {}
+    _default_lock = threading.Lock()
+
+    def __init__(self, index=0):
+        p = C.c_void_p()
+        check(lib.ft_ctx_create(int(index), C.byref(p)))
+        self._ctx = p
+        self.index = int(index)
+
+    @classmethod
+    def default(cls, index=0):
+        with cls._default_lock:
+            if index not in cls._default:
+                cls._default[index] = Device(index)
+            return cls._default[index]
+
+    def close(self):
+        if self._ctx:
+            lib.ft_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def set_stream(self, hip_stream):
+        check(lib.ft_ctx_set_stream(self._ctx, C.c_void_p(hip_stream)))
+
+    # constructor twins ---------------------------------------------------------------------------
+    def sphere(self, c, r): return check(lib.ft_form_sphere(self._ctx, C.byref(_lib.Sphere(_vec(c), r))))
+    def capsule(self, a, b, r): return check(lib.ft_form_capsule(self._ctx, C.byref(_lib.Capsule(_vec(a), _vec(b), r))))
+    def torus(self, c, n, R, r): return check(lib.ft_form_torus(self._ctx, C.byref(_lib.Torus(_vec(c), _vec(n), R, r))))
+    def triangle(self, a, b, c, r): return check(lib.ft_form_triangle(self._ctx, C.byref(_lib.Triangle(_vec(a), _vec(b), _vec(c), r))))
+    def box(self, c, h): return check(lib.ft_form_box(self._ctx, C.byref(_lib.Box(_vec(c), _vec(h)))))
+    def form_union(self, hs): return check(lib.ft_form_union(self._ctx, *_handles(hs)))
+    def form_subtract(self, a, b): return check(lib.ft_form_subtract(self._ctx, a, b))
+    def form_intersect(self, hs): return check(lib.ft_form_intersect(self._ctx, *_handles(hs)))
+    def form_union_smooth(self, k, hs): return check(lib.ft_form_union_smooth(self._ctx, k, *_handles(hs)))
+    def material_solid(self, rgb): return check(lib.ft_material_solid(self._ctx, _f3(rgb)))
+    def object_create(self, m, f): return check(lib.ft_object_create(self._ctx, m, f))
+    def object_union(self, hs): return check(lib.ft_object_union(self._ctx, *_handles(hs)))
+    def object_subtract(self, o, f): return check(lib.ft_object_subtract(self._ctx, o, f))
+    def object_intersect(self, o, hs): return check(lib.ft_object_intersect(self._ctx, o, *_handles(hs)))
+    def light_directional(self, d, c): return check(lib.ft_light_directional(self._ctx, _f3(d), _f3(c)))
+    def light_point(self, p, c): return check(lib.ft_light_point(self._ctx, _f3(p), _f3(c)))
+
+    def form_boundary(self, h):
+        b = _lib.Boundary()
+        check(lib.ft_form_boundary(self._ctx, h, C.byref(b)))
+        return (b.center.x, b.center.y, b.center.z, b.radius)
+
+    def object_form(self, h): return check(lib.ft_object_form(self._ctx, h))
+
+    def scene(self, scene):
+        """realise + flatten + upload an SdfScene; cached per device."""
+        with scene._lock:
+            got = scene._realised.get(id(self))
+            if got is None:
+                memo = {}
+                obj = realise(scene.Object, self, memo)
+                lights = [realise(l, self, memo) for l in scene.Lights]
+                got = DeviceScene(self, obj, scene.BackgroundColor, lights)
+                scene._realised[id(self)] = got
+            return got
+
+    def math_eval(self, op, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float32)
+            yp = y.ctypes.data_as(C.c_void_p)
+        check(lib.ft_math_eval(self._ctx, op, x.ctypes.data_as(C.c_void_p), yp, x.size, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class DeviceScene:
+    """ft_scene: the flattened immutable scene resident in HBM."""
+
+    def __init__(self, device, obj, bg, lights):
+        self.device = device
+        p = C.c_void_p()
+        hs, n = _handles(lights)
+        check(lib.ft_scene_create(device._ctx, obj, _f3(bg), hs, n, C.byref(p)))
+        self._scene = p
+
+    def close(self):
+        if self._scene:
+            lib.ft_scene_destroy(self._scene)
+            self._scene = None
+
+    def info(self):
+        i = _lib.SceneInfo()
+        check(lib.ft_scene_info_get(self._scene, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in i._fields_}
+
+    def grid(self, g=0):
+        info = (C.c_float * 6)()
+        counts = (C.c_int32 * 3)()
+        nc, ni = C.c_int32(), C.c_int32()
+        check(lib.ft_scene_grid_shape(self._scene, g, info, counts, C.byref(nc), C.byref(ni)))
+        cell_start = np.empty(nc.value + 1, np.uint32)
+        centers = np.empty((nc.value, 3), np.float32)
+        lower = np.empty(ni.value, np.float32)
+        child = np.empty(ni.value, np.int32)
+        check(lib.ft_scene_grid_dump(self._scene, g, *(a.ctypes.data_as(C.c_void_p) for a in (cell_start, centers, lower, child))))
+        return {"aabbMin": np.array(info[0:3], np.float32), "cellSizeInv": np.array(info[3:6], np.float32),
+                "counts": tuple(counts), "cell_start": cell_start, "centers": centers, "lower": lower, "child": child}
+
+    def _params(self, imageSize, epsilon, length, x0=0, n_columns=None, stripe_width=None, stripe_ranks=1, stripe_rank=0):
+        W, H = int(imageSize.X), int(imageSize.Y)
+        if n_columns is None:
+            n_columns = W - x0 if stripe_ranks == 1 else W // stripe_ranks
+        if stripe_width is None:
+            stripe_width = n_columns
+        return _lib.RenderParams(W, H, int(x0), int(n_columns), int(stripe_width), int(stripe_ranks), int(stripe_rank),
+                                 1, float(epsilon), float(length), 0, 0.0)
+
+    def render(self, epsilon, length, imageSize, camera, **tiling):
+        """Image.render (Image.fs:26-35) -> (FColor[X,Y] as float32 [n_columns, Y, 3], stats dict)."""
+        p = self._params(imageSize, epsilon, length, **tiling)
+        out = np.empty((p.n_columns, p.height, 3), np.float32)
+        st = _lib.Stats()
+        check(lib.ft_render(self.device._ctx, self._scene, C.byref(camera._c), C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, st.as_dict()
+
+    def render_device(self, epsilon, length, imageSize, camera, d_out_ptr, **tiling):
+        """asynchronous render into device memory (pointer as int); pair with collect_stats()."""
+        p = self._params(imageSize, epsilon, length, **tiling)
+        check(lib.ft_render_device(self.device._ctx, self._scene, C.byref(camera._c), C.byref(p), C.c_void_p(d_out_ptr)))
+        return p.n_columns
+
+    def collect_stats(self):
+        st = _lib.Stats()
+        check(lib.ft_collect_stats(self.device._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def trace_rays(self, rays):
+        """SdfScene.trace over n rays given as float32 [n, 8] (Origin, Direction, Length, Epsilon)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.empty((rays.shape[0], 3), np.float32)
+        st = _lib.Stats()
+        check(lib.ft_trace_rays(self.device._ctx, self._scene, rays.ctypes.data_as(C.c_void_p), rays.shape[0],
+                                out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, st.as_dict()
+
+    def eval_distance(self, points):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        d = np.empty(pts.shape[0], np.float32)
+        m = np.empty(pts.shape[0], np.int32)
+        check(lib.ft_eval_distance(self.device._ctx, self._scene, pts.ctypes.data_as(C.c_void_p), pts.shape[0],
+                                   d.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p)))
+        return d, m
+
+
+class SceneTrace:
+    """The value `SdfScene.trace scene`: callable on one ray (8 floats) -> FColor."""
+
+    def __init__(self, scene, device=None):
+        self.scene = scene
+        self.device = device
+
+    def resolve(self):
+        dev = self.device if self.device is not None else Device.default(0)
+        return dev.scene(self.scene)
+
+    def __call__(self, ray):
+        out, _ = self.resolve().trace_rays(np.asarray(ray, np.float32).reshape(1, 8))
+        return FColor(tuple(float(c) for c in out[0]))
+
+
+# --------------------------------------------------------------------------------------------------
+# Camera.fs / Image.fs
+# --------------------------------------------------------------------------------------------------
+class Lens:
+    def __init__(self, NearPlaneSize):
+        self.NearPlaneSize = float(NearPlaneSize)
+
+    @staticmethod
+    def create(fieldOfView):
+        """Camera.fs:11-14: sin(fov * 0.5) — radians, as in the reference (Program.fs:21 passes 60.0f)."""
+        return Lens(lib.ft_lens_create(float(np.float32(fieldOfView))))
+
+
+class Camera:
+    def __init__(self, c):
+        self._c = c
+
+    @staticmethod
+    def lookAt(Position, LookAt, Up, Lens):
+        c = _lib.CameraS()
+        check(lib.ft_camera_look_at(_f3(_v3(Position)), _f3(_v3(LookAt)), _f3(_v3(Up)), Lens.NearPlaneSize, C.byref(c)))
+        return Camera(c)
+
+    def as_array(self):
+        return np.frombuffer(bytes(self._c), dtype=np.float32).copy()
+
+    Position = property(lambda s: (s._c.position.x, s._c.position.y, s._c.position.z))
+    Forward = property(lambda s: (s._c.forward.x, s._c.forward.y, s._c.forward.z))
+    UpScaled = property(lambda s: (s._c.up_scaled.x, s._c.up_scaled.y, s._c.up_scaled.z))
+    RightScaled = property(lambda s: (s._c.right_scaled.x, s._c.right_scaled.y, s._c.right_scaled.z))
+
+
+class ImageSize:
+    def __init__(self, X, Y):
+        self.X, self.Y = int(X), int(Y)
+
+
+class Image:
+    @staticmethod
+    def render(epsilon, length, imageSize, camera, trace):
+        """Image.render epsilon length imageSize camera trace (Image.fs:26-35).  `trace` must be the
+        value of SdfScene.trace (an opaque Python closure cannot run on the GPU); returns the
+        FColor[X,Y] image as a float32 array [X, Y, 3]."""
+        if not isinstance(trace, SceneTrace):
+            raise TypeError("Image.render needs `SdfScene.trace scene`; arbitrary closures have no GPU form")
+        img, _ = trace.resolve().render(epsilon, length, imageSize, camera)
+        return img
+
+    @staticmethod
+    def renderScene(epsilon, length, imageSize, camera, scene, device=None):
+        return Image.render(epsilon, length, imageSize, camera, SdfScene.trace(scene, device))

@@ -1,0 +1,457 @@
+// capi.cpp — the C ABI of libfraytracer_hip.so (include/fraytracer_hip.h).  Plain host C++;
+// device code and launchers live in kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fraytracer_hip.h"
+#include "ft_kernels.h"
+#include "scene.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+int setErr(int code, const std::string& m) { g_err = m; return code; }
+int hipFail(hipError_t e, const char* what) {
+    return setErr(FT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hipFail(_e, #expr); } while (0)
+
+inline f3 tof3(const float* p) { return mk3(p[0], p[1], p[2]); }
+inline f3 tof3(const ft_vec3& v) { return mk3(v.x, v.y, v.z); }
+
+}  // namespace
+
+struct ft_ctx {
+    int device = -1;
+    bool hasDevice = false;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int numCUs = 0;
+    ft::Builder builder;
+    uint32_t* dCounter = nullptr;
+    FtStatsDev* dStats = nullptr;
+    void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
+};
+
+struct ft_scene {
+    ft_ctx* ctx = nullptr;
+    ft::FlatScene flat;
+    void* dBlob = nullptr;
+    FtSceneDev dev{};
+};
+
+namespace {
+
+int requireDevice(ft_ctx* c) {
+    if (!c) return setErr(FT_ERR_INVALID, "null context");
+    if (!c->hasDevice) return setErr(FT_ERR_NO_DEVICE, "context has no GPU: libfraytracer_hip has no CPU fallback");
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hipFail(e, "hipSetDevice");
+    return FT_OK;
+}
+
+int ensureScratch(ft_ctx* c, size_t bytes) {
+    if (bytes <= c->scratchBytes) return FT_OK;
+    if (c->scratch) { HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratchBytes = 0; }
+    HIP_TRY(hipMalloc(&c->scratch, bytes));
+    c->scratchBytes = bytes;
+    return FT_OK;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <class T> size_t placed(size_t& cursor, const std::vector<T>& v) {
+    const size_t at = cursor;
+    cursor = align256(cursor + std::max<size_t>(v.size() * sizeof(T), 16));
+    return at;
+}
+
+int uploadScene(ft_ctx* c, ft_scene* s) {
+    const ft::FlatScene& f = s->flat;
+    size_t cur = 0;
+    const size_t oInstr = placed(cur, f.instr), oConsts = placed(cur, f.consts), oGrids = placed(cur, f.grids),
+                 oKids = placed(cur, f.children), oCtr = placed(cur, f.cellCenters), oStart = placed(cur, f.cellStart),
+                 oItems = placed(cur, f.items), oLights = placed(cur, f.lights), oMats = placed(cur, f.materials);
+    std::vector<unsigned char> host(cur, 0);
+    auto put = [&](size_t at, const void* p, size_t n) { if (n) memcpy(host.data() + at, p, n); };
+    put(oInstr, f.instr.data(), f.instr.size() * sizeof(FtInstr));
+    put(oConsts, f.consts.data(), f.consts.size() * 4);
+    put(oGrids, f.grids.data(), f.grids.size() * sizeof(FtGrid));
+    put(oKids, f.children.data(), f.children.size() * sizeof(FtChild));
+    put(oCtr, f.cellCenters.data(), f.cellCenters.size() * 4);
+    put(oStart, f.cellStart.data(), f.cellStart.size() * 4);
+    put(oItems, f.items.data(), f.items.size() * sizeof(FtItem));
+    put(oLights, f.lights.data(), f.lights.size() * sizeof(FtLight));
+    put(oMats, f.materials.data(), f.materials.size() * 4);
+    FtSceneDev& d = s->dev;
+    d = FtSceneDev{};
+    d.nInstr = (uint32_t)f.instr.size(); d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
+    d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
+    if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(&s->dBlob, cur));
+    HIP_TRY(hipMemcpy(s->dBlob, host.data(), cur, hipMemcpyHostToDevice));
+    unsigned char* b = static_cast<unsigned char*>(s->dBlob);
+    d.instr = reinterpret_cast<const FtInstr*>(b + oInstr);
+    d.consts = reinterpret_cast<const float*>(b + oConsts);
+    d.grids = reinterpret_cast<const FtGrid*>(b + oGrids);
+    d.children = reinterpret_cast<const FtChild*>(b + oKids);
+    d.cellCenters = reinterpret_cast<const float*>(b + oCtr);
+    d.cellStart = reinterpret_cast<const uint32_t*>(b + oStart);
+    d.items = reinterpret_cast<const FtItem*>(b + oItems);
+    d.lights = reinterpret_cast<const FtLight*>(b + oLights);
+    d.materials = reinterpret_cast<const float*>(b + oMats);
+    return FT_OK;
+}
+
+size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8; }
+
+int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
+    if (!c->eventPool.empty()) { a = c->eventPool.back().first; b = c->eventPool.back().second; c->eventPool.pop_back(); return FT_OK; }
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    return FT_OK;
+}
+
+// launch the persistent trace kernel over nJobs jobs
+int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
+    int perCU = 0;
+    HIP_TRY(ft_trace_occupancy(ldsBytes(s), &perCU));
+    perCU = std::max(1, std::min(perCU, 8));
+    const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
+    const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
+    const uint64_t waves = (uint64_t)blocks * (FT_BLOCK / 64);
+    uint64_t chunk = a.nJobs / (waves * 8);
+    chunk = std::max<uint64_t>(64, std::min<uint64_t>(chunk, 1024)) & ~(uint64_t)63;
+    a.chunk = (uint32_t)chunk;
+    a.counter = c->dCounter;
+    a.stats = c->dStats;
+    a.S = s->dev;
+    HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
+    hipEvent_t e0, e1;
+    int rc = acquireEvents(c, e0, e1); if (rc) return rc;
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    HIP_TRY(ft_launch_trace(&a, blocks, ldsBytes(s), c->stream));
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    c->events.emplace_back(e0, e1);
+    return FT_OK;
+}
+
+int checkParams(const ft_render_params* p) {
+    if (!p) return setErr(FT_ERR_INVALID, "null render params");
+    if (p->width <= 0 || p->height <= 0 || p->n_columns <= 0) return setErr(FT_ERR_INVALID, "empty image");
+    if (p->stripe_width <= 0 || p->stripe_ranks <= 0 || p->stripe_rank < 0 || p->stripe_rank >= p->stripe_ranks)
+        return setErr(FT_ERR_INVALID, "bad stripe description");
+    if (p->spp != 1 || p->ao_samples != 0) return setErr(FT_ERR_UNSUPPORTED, "spp > 1 / ambient occlusion are extensions not built yet");
+    // last local column must map inside the image
+    const int64_t c = (int64_t)p->n_columns - 1;
+    const int64_t x = p->x0 + (c / p->stripe_width) * (int64_t)p->stripe_width * p->stripe_ranks + (int64_t)p->stripe_rank * p->stripe_width + c % p->stripe_width;
+    if (p->x0 < 0 || x >= p->width) return setErr(FT_ERR_INVALID, "column range leaves the image");
+    const uint64_t tiles = (uint64_t)((p->n_columns + 7) / 8) * (uint64_t)((p->height + 7) / 8);
+    if (tiles * 64 >= 0xFFFF0000ull) return setErr(FT_ERR_UNSUPPORTED, "more than 2^32 pixels in one call");
+    return FT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ft_abi_version(void) { return FT_ABI_VERSION; }
+const char* ft_last_error(void) { return g_err.c_str(); }
+
+int ft_ctx_create(int device, ft_ctx** out) {
+    if (!out) return setErr(FT_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    ft_ctx* c = new ft_ctx();
+    c->device = device;
+    if (device >= 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) { delete c; return setErr(FT_ERR_NO_DEVICE, "no HIP device visible (libfraytracer_hip has no CPU fallback)"); }
+        if (device >= n) { delete c; return setErr(FT_ERR_INVALID, "device ordinal out of range"); }
+        if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { delete c; return hipFail(e, "hipGetDeviceProperties"); }
+        c->numCUs = prop.multiProcessorCount;
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipFail(e, "hipStreamCreate"); }
+        c->ownStream = true;
+        if ((e = hipMalloc((void**)&c->dCounter, 256)) != hipSuccess) { delete c; return hipFail(e, "hipMalloc"); }
+        if ((e = hipMalloc((void**)&c->dStats, sizeof(FtStatsDev))) != hipSuccess) { delete c; return hipFail(e, "hipMalloc"); }
+        if ((e = hipMemset(c->dStats, 0, sizeof(FtStatsDev))) != hipSuccess) { delete c; return hipFail(e, "hipMemset"); }
+        c->hasDevice = true;
+    }
+    *out = c;
+    return FT_OK;
+}
+
+void ft_ctx_destroy(ft_ctx* c) {
+    if (!c) return;
+    if (c->hasDevice) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& p : c->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        for (auto& p : c->eventPool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        if (c->scratch) (void)hipFree(c->scratch);
+        if (c->dCounter) (void)hipFree(c->dCounter);
+        if (c->dStats) (void)hipFree(c->dStats);
+        if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int ft_ctx_set_stream(ft_ctx* c, void* hip_stream) {
+    int rc = requireDevice(c); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ownStream && c->stream) { HIP_TRY(hipStreamDestroy(c->stream)); }
+    if (hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->ownStream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
+    return FT_OK;
+}
+
+// ---- scene construction ------------------------------------------------------------------------
+#define CTX_OR_FAIL(c) do { if (!(c)) return setErr(FT_ERR_INVALID, "null context"); } while (0)
+static int builderResult(ft_ctx* c, int h) { if (h < 0) g_err = c->builder.err; return h; }
+
+ft_handle ft_form_sphere(ft_ctx* c, const ft_sphere* s) {
+    CTX_OR_FAIL(c); if (!s) return setErr(FT_ERR_INVALID, "null primitive");
+    return c->builder.sphere(tof3(s->center), s->radius);
+}
+ft_handle ft_form_capsule(ft_ctx* c, const ft_capsule* s) {
+    CTX_OR_FAIL(c); if (!s) return setErr(FT_ERR_INVALID, "null primitive");
+    return c->builder.capsule(tof3(s->from), tof3(s->to), s->radius);
+}
+ft_handle ft_form_torus(ft_ctx* c, const ft_torus* s) {
+    CTX_OR_FAIL(c); if (!s) return setErr(FT_ERR_INVALID, "null primitive");
+    return c->builder.torus(tof3(s->center), tof3(s->normal), s->major_radius, s->minor_radius);
+}
+ft_handle ft_form_triangle(ft_ctx* c, const ft_triangle* s) {
+    CTX_OR_FAIL(c); if (!s) return setErr(FT_ERR_INVALID, "null primitive");
+    return c->builder.triangle(tof3(s->v1), tof3(s->v2), tof3(s->v3), s->radius);
+}
+ft_handle ft_form_box(ft_ctx* c, const ft_box* s) {
+    CTX_OR_FAIL(c); if (!s) return setErr(FT_ERR_INVALID, "null primitive");
+    return c->builder.box(tof3(s->center), tof3(s->half_extent));
+}
+ft_handle ft_form_union(ft_ctx* c, const ft_handle* forms, int32_t n) { CTX_OR_FAIL(c); return builderResult(c, c->builder.formUnion(forms, n)); }
+ft_handle ft_form_subtract(ft_ctx* c, ft_handle a, ft_handle b) { CTX_OR_FAIL(c); return builderResult(c, c->builder.formSubtract(a, b)); }
+ft_handle ft_form_intersect(ft_ctx* c, const ft_handle* forms, int32_t n) { CTX_OR_FAIL(c); return builderResult(c, c->builder.formIntersect(forms, n)); }
+ft_handle ft_form_union_smooth(ft_ctx* c, float strength, const ft_handle* forms, int32_t n) {
+    CTX_OR_FAIL(c); return builderResult(c, c->builder.formUnionSmooth(strength, forms, n));
+}
+int ft_form_boundary(ft_ctx* c, ft_handle form, ft_boundary* out) {
+    CTX_OR_FAIL(c);
+    if (!c->builder.okForm(form) || !out) return setErr(FT_ERR_INVALID, "invalid form handle");
+    const ft::Boundary& b = c->builder.forms[form].boundary;
+    out->center.x = b.center.x; out->center.y = b.center.y; out->center.z = b.center.z; out->radius = b.radius;
+    return FT_OK;
+}
+ft_handle ft_material_solid(ft_ctx* c, const float rgb[3]) { CTX_OR_FAIL(c); if (!rgb) return setErr(FT_ERR_INVALID, "null colour"); return c->builder.materialSolid(tof3(rgb)); }
+ft_handle ft_object_create(ft_ctx* c, ft_handle material, ft_handle form) { CTX_OR_FAIL(c); return builderResult(c, c->builder.objectCreate(material, form)); }
+ft_handle ft_object_union(ft_ctx* c, const ft_handle* objs, int32_t n) { CTX_OR_FAIL(c); return builderResult(c, c->builder.objectUnion(objs, n)); }
+ft_handle ft_object_subtract(ft_ctx* c, ft_handle obj, ft_handle form) { CTX_OR_FAIL(c); return builderResult(c, c->builder.objectSubtract(obj, form)); }
+ft_handle ft_object_intersect(ft_ctx* c, ft_handle obj, const ft_handle* forms, int32_t n) {
+    CTX_OR_FAIL(c); return builderResult(c, c->builder.objectIntersect(obj, forms, n));
+}
+ft_handle ft_object_form(ft_ctx* c, ft_handle obj) {
+    CTX_OR_FAIL(c);
+    if (!c->builder.okObject(obj)) return setErr(FT_ERR_INVALID, "invalid object handle");
+    return c->builder.objects[obj].form;
+}
+ft_handle ft_light_directional(ft_ctx* c, const float d[3], const float rgb[3]) {
+    CTX_OR_FAIL(c); if (!d || !rgb) return setErr(FT_ERR_INVALID, "null argument");
+    return c->builder.lightDirectional(tof3(d), tof3(rgb));
+}
+ft_handle ft_light_point(ft_ctx* c, const float p[3], const float rgb[3]) {
+    CTX_OR_FAIL(c); if (!p || !rgb) return setErr(FT_ERR_INVALID, "null argument");
+    return c->builder.lightPoint(tof3(p), tof3(rgb));
+}
+
+int ft_scene_create(ft_ctx* c, ft_handle object, const float bg[3], const ft_handle* lights, int32_t n, ft_scene** out) {
+    CTX_OR_FAIL(c);
+    if (!out || !bg || n < 0 || (n > 0 && !lights)) return setErr(FT_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    ft_scene* s = new ft_scene();
+    s->ctx = c;
+    std::string err;
+    if (!ft::flatten(c->builder, object, bg, lights, n, s->flat, err)) { delete s; return setErr(FT_ERR_UNSUPPORTED, err); }
+    int rc = uploadScene(c, s);
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return FT_OK;
+}
+
+int ft_scene_clone(const ft_scene* src, ft_ctx* dst, ft_scene** out) {
+    if (!src || !dst || !out) return setErr(FT_ERR_INVALID, "bad argument");
+    ft_scene* s = new ft_scene();
+    s->ctx = dst;
+    s->flat = src->flat;
+    int rc = uploadScene(dst, s);
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return FT_OK;
+}
+
+void ft_scene_destroy(ft_scene* s) {
+    if (!s) return;
+    if (s->dBlob) { (void)hipSetDevice(s->ctx->device); (void)hipFree(s->dBlob); }
+    delete s;
+}
+
+float ft_lens_create(float fov) { return ft::lensCreate(fov); }
+int ft_camera_look_at(const float pos[3], const float look[3], const float up[3], float nps, ft_camera* out) {
+    if (!pos || !look || !up || !out) return setErr(FT_ERR_INVALID, "null argument");
+    f3 o[4];
+    ft::cameraLookAt(tof3(pos), tof3(look), tof3(up), nps, o);
+    out->position = ft_vec3{o[0].x, o[0].y, o[0].z}; out->forward = ft_vec3{o[1].x, o[1].y, o[1].z};
+    out->up_scaled = ft_vec3{o[2].x, o[2].y, o[2].z}; out->right_scaled = ft_vec3{o[3].x, o[3].y, o[3].z};
+    return FT_OK;
+}
+
+// ---- hot path ------------------------------------------------------------------------------------
+int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, void* d_out) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!s || s->ctx != c || !cam || !d_out) return setErr(FT_ERR_INVALID, "bad argument (scene must belong to this context)");
+    if ((rc = checkParams(p))) return rc;
+    FtRenderArgs a{};
+    memcpy(a.cam, cam, sizeof(float) * 12);
+    a.W = p->width; a.H = p->height; a.x0 = p->x0; a.nCols = p->n_columns;
+    a.stripeW = (uint32_t)p->stripe_width; a.stripeRanks = (uint32_t)p->stripe_ranks; a.stripeRank = (uint32_t)p->stripe_rank;
+    a.mode = 0;
+    a.maxSize = (float)std::max(p->width, p->height);              // Image.fs:18
+    a.eps = p->epsilon; a.length = p->length;
+    a.out = static_cast<float*>(d_out);
+    a.tilesY = (uint32_t)((p->height + 7) / 8);
+    a.nJobs = (uint32_t)((p->n_columns + 7) / 8) * a.tilesY * 64u;
+    return launchTrace(c, s, a);
+}
+
+int ft_collect_stats(ft_ctx* c, ft_stats* st) {
+    int rc = requireDevice(c); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    for (auto& p : c->events) {
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
+        ms += t;
+        c->eventPool.push_back(p);
+    }
+    c->events.clear();
+    FtStatsDev h{};
+    HIP_TRY(hipMemcpy(&h, c->dStats, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->dStats, 0, sizeof(FtStatsDev)));
+    if (st) {
+        st->rays_primary = h.rays_primary; st->rays_shadow = h.rays_shadow; st->rays_ext = h.rays_ext;
+        st->hits_primary = h.hits_primary; st->hits_shadow = h.hits_shadow; st->sdf_evals = h.sdf_evals;
+        st->flags = h.flags; st->kernel_ms = ms; st->reserved = 0.0f;
+    }
+    return FT_OK;
+}
+
+int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, float* out, ft_stats* st) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!out) return setErr(FT_ERR_INVALID, "null output");
+    if ((rc = checkParams(p))) return rc;
+    const size_t bytes = (size_t)p->n_columns * p->height * 3 * sizeof(float);
+    if ((rc = ensureScratch(c, bytes))) return rc;
+    if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    return ft_collect_stats(c, st);
+}
+
+int ft_trace_rays(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, float* out, ft_stats* st) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!s || s->ctx != c || !rays || !out || n < 0) return setErr(FT_ERR_INVALID, "bad argument");
+    if (n == 0) { if (st) memset(st, 0, sizeof(*st)); return FT_OK; }
+    if (n >= 0xFFFF0000ll) return setErr(FT_ERR_UNSUPPORTED, "more than 2^32 rays in one call");
+    const size_t rayBytes = align256((size_t)n * sizeof(ft_ray)), outBytes = (size_t)n * 3 * sizeof(float);
+    if ((rc = ensureScratch(c, rayBytes + outBytes))) return rc;
+    unsigned char* base = static_cast<unsigned char*>(c->scratch);
+    HIP_TRY(hipMemcpyAsync(base, rays, (size_t)n * sizeof(ft_ray), hipMemcpyHostToDevice, c->stream));
+    FtRenderArgs a{};
+    a.mode = 1; a.rays = reinterpret_cast<const ft_ray*>(base); a.out = reinterpret_cast<float*>(base + rayBytes);
+    a.nJobs = (uint32_t)n; a.stripeW = 1; a.stripeRanks = 1; a.tilesY = 1; a.H = 1; a.W = 1; a.nCols = 1; a.maxSize = 1.0f;
+    if ((rc = launchTrace(c, s, a))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, base + rayBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
+    return ft_collect_stats(c, st);
+}
+
+int ft_eval_distance(ft_ctx* c, const ft_scene* s, const ft_vec3* pts, int64_t n, float* outD, int32_t* outM) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!s || s->ctx != c || !pts || !outD || n < 0) return setErr(FT_ERR_INVALID, "bad argument");
+    if (n == 0) return FT_OK;
+    const size_t pBytes = align256((size_t)n * 12), dBytes = align256((size_t)n * 4), mBytes = (size_t)n * 4;
+    if ((rc = ensureScratch(c, pBytes + dBytes + mBytes))) return rc;
+    unsigned char* base = static_cast<unsigned char*>(c->scratch);
+    HIP_TRY(hipMemcpyAsync(base, pts, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + FT_BLOCK - 1) / FT_BLOCK, (int64_t)c->numCUs * 8);
+    HIP_TRY(ft_launch_eval_points(&s->dev, reinterpret_cast<const float*>(base), n, reinterpret_cast<float*>(base + pBytes),
+                                  reinterpret_cast<int*>(base + pBytes + dBytes), blocks, ldsBytes(s), c->stream));
+    HIP_TRY(hipMemcpyAsync(outD, base + pBytes, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (outM) HIP_TRY(hipMemcpyAsync(outM, base + pBytes + dBytes, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FT_OK;
+}
+
+int ft_math_eval(ft_ctx* c, int32_t op, const float* x, const float* y, int64_t n, float* out) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!x || !out || n < 0 || op < 0 || op > 3 || (op == 3 && !y)) return setErr(FT_ERR_INVALID, "bad argument");
+    if (n == 0) return FT_OK;
+    const size_t b = align256((size_t)n * 4);
+    if ((rc = ensureScratch(c, 3 * b))) return rc;
+    unsigned char* base = static_cast<unsigned char*>(c->scratch);
+    HIP_TRY(hipMemcpyAsync(base, x, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (y) HIP_TRY(hipMemcpyAsync(base + b, y, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(ft_launch_math(op, reinterpret_cast<const float*>(base), reinterpret_cast<const float*>(base + b), n,
+                           reinterpret_cast<float*>(base + 2 * b), c->stream));
+    HIP_TRY(hipMemcpyAsync(out, base + 2 * b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FT_OK;
+}
+
+// ---- internal hooks for multi.cpp (not part of the public ABI) ------------------------------------------
+int ft_ctx_device_(const ft_ctx* c) { return (c && c->hasDevice) ? c->device : -1; }
+void* ft_ctx_stream_(const ft_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void ft_set_error_(int, const char* msg) { g_err = msg ? msg : ""; }
+
+// ---- introspection ---------------------------------------------------------------------------------
+int ft_scene_info_get(const ft_scene* s, ft_scene_info* o) {
+    if (!s || !o) return setErr(FT_ERR_INVALID, "null argument");
+    const ft::FlatScene& f = s->flat;
+    o->n_instr = (int32_t)f.instr.size(); o->n_slots = (int32_t)f.nSlots; o->n_consts = (int32_t)f.consts.size();
+    o->n_grids = (int32_t)f.grids.size(); o->n_children = (int32_t)f.children.size(); o->n_cells = (int32_t)(f.cellCenters.size() / 3);
+    o->n_items = (int32_t)f.items.size(); o->n_lights = (int32_t)f.lights.size(); o->n_materials = (int32_t)(f.materials.size() / 3);
+    o->fast_path = (int32_t)f.fastPath;
+    return FT_OK;
+}
+
+int ft_scene_grid_shape(const ft_scene* s, int32_t g, float info[6], int32_t counts[3], int32_t* nCells, int32_t* nItems) {
+    if (!s || g < 0 || (size_t)g >= s->flat.grids.size()) return setErr(FT_ERR_INVALID, "bad grid index");
+    const FtGrid& G = s->flat.grids[g];
+    for (int i = 0; i < 3; ++i) { info[i] = G.aabbMin[i]; info[3 + i] = G.cellSizeInv[i]; counts[i] = G.count[i]; }
+    const int32_t nc = G.count[0] * G.count[1] * G.count[2];
+    if (nCells) *nCells = nc;
+    if (nItems) *nItems = (int32_t)(s->flat.cellStart[G.cellBase + nc] - s->flat.cellStart[G.cellBase]);
+    return FT_OK;
+}
+
+int ft_scene_grid_dump(const ft_scene* s, int32_t g, uint32_t* cellStart, float* centers, float* lower, int32_t* child) {
+    if (!s || g < 0 || (size_t)g >= s->flat.grids.size()) return setErr(FT_ERR_INVALID, "bad grid index");
+    const ft::FlatScene& f = s->flat;
+    const FtGrid& G = f.grids[g];
+    const uint32_t nc = (uint32_t)(G.count[0] * G.count[1] * G.count[2]);
+    const uint32_t first = f.cellStart[G.cellBase];
+    for (uint32_t c = 0; c <= nc; ++c) cellStart[c] = f.cellStart[G.cellBase + c] - first;
+    memcpy(centers, f.cellCenters.data() + 3 * (size_t)G.cellBase, (size_t)nc * 12);
+    const uint32_t ni = f.cellStart[G.cellBase + nc] - first;
+    for (uint32_t i = 0; i < ni; ++i) { lower[i] = f.items[first + i].lowerBound; child[i] = (int32_t)f.items[first + i].child; }
+    return FT_OK;
+}
+
+}  // extern "C"

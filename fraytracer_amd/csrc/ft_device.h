@@ -1,0 +1,93 @@
+// ft_device.h — layout of the flattened, immutable scene in HBM (shared by host flattener and kernels).
+//
+// The F# scene is a tree of closures (Types.fs:40-79).  It is flattened once into
+//   * a linear, wave-uniform program of FtInstr over per-lane value slots (one slot per nesting level),
+//   * a float constant pool holding what each primitive closure captures (SdfForm.fs:148-149,
+//     182-188, 216-225), laid out per type with a fixed stride so a uniform loop reads it with
+//     scalar loads and a per-lane union loop gathers it,
+//   * for every `union` a uniform grid in CSR form (SdfBoundary.fs:225-274): cellStart / items
+//     (LowerBound, child) sorted per cell, cell centres, and a child table (boundary, type, data,
+//     material).
+// Everything is read-only during rendering and a few KB to a few MB, i.e. L2 / scalar-cache resident.
+#pragma once
+#include <stdint.h>
+
+enum FtOp : uint32_t {
+    FT_OP_PRIM = 0,      // slot[dst] = prim(type, data)
+    FT_OP_SETLEAF,       // leaf[dst] = aux                              (SdfObject.create: one solid material)
+    FT_OP_SMOOTH_RUN,    // acc = flags&1 ? 0 : slot[dst]; for i<count: acc += exp(f0 * prim_i); slot[dst] = acc
+    FT_OP_SMOOTH_ADD,    // slot[dst] = (flags&1 ? 0 : slot[dst]) + exp(f0 * slot[src])
+    FT_OP_SMOOTH_FIN,    // slot[dst] = -log(slot[dst]) * f0             (SdfForm.fs:82)
+    FT_OP_SUBTRACT,      // slot[dst] = Max(-slot[src], slot[dst])       (SdfForm.fs:46-47)
+    FT_OP_ISECT_RUN,     // for i<count: if slot[dst] < maxDist(bound_i) then slot[dst] = Max(slot[dst], prim_i)  (SdfForm.fs:60-63)
+    FT_OP_ISECT_APPLY,   // same test with bound at consts[aux], value = slot[src]
+    FT_OP_UNION,         // slot[dst], leaf[dst] = grid union aux        (SdfForm.fs:22-34 + SdfObject.fs:27-46)
+};
+
+enum FtPrim : uint32_t {
+    FT_PR_SPHERE = 0, FT_PR_CAPSULE = 1, FT_PR_TORUS = 2, FT_PR_TRIANGLE = 3, FT_PR_BOX = 4,
+    FT_PR_SLOT = 15      // union child that is itself a combinator: value pre-evaluated in slot `data`
+};
+
+// constant-pool strides (floats) per primitive type
+#define FT_STRIDE_SPHERE 4      // C.xyz, r
+#define FT_STRIDE_CAPSULE 12    // From.xyz, r | dir.xyz, _ | dirInv.xyz, _
+#define FT_STRIDE_TORUS 12      // C.xyz, R | N.xyz, r | planeD, _, _, _
+#define FT_STRIDE_TRIANGLE 52   // V1,r | V2,_ | V3,_ | v21 | v32 | v13 | v21' | v32' | v13' | nor | n21 | n32 | n13 (xyz_ each)
+#define FT_STRIDE_BOX 8         // C.xyz, _ | H.xyz, _
+
+struct FtInstr {                // 12 dwords
+    uint32_t op, dst, src, type;
+    uint32_t count, data, aux, flags;
+    float f0, f1;
+    uint32_t pad0, pad1;
+};
+
+struct FtGrid {                 // 12 dwords
+    float aabbMin[3];
+    float cellSizeInv[3];
+    int32_t count[3];
+    uint32_t cellBase;          // first cell of this grid in cellStart / cellCenters
+    uint32_t childBase;         // first child of this union in children[]
+    uint32_t nChildren;
+};
+
+struct FtChild {                // 8 dwords
+    float bc[3]; float br;      // child.Boundary
+    uint32_t type;              // FtPrim
+    uint32_t data;              // constant-pool offset, or slot index for FT_PR_SLOT
+    uint32_t mat;               // material index if the child is `SdfObject.create solid prim`
+    uint32_t pad;
+};
+
+struct FtItem { float lowerBound; uint32_t child; };
+
+enum FtLightType : uint32_t { FT_LIGHT_DIRECTIONAL = 0, FT_LIGHT_POINT = 1 };
+struct FtLight {                // 8 dwords
+    uint32_t type;
+    float v[3];                 // directional: normalize(-direction) (SdfLight.fs:7); point: position
+    float color[3];
+    float pad;
+};
+
+struct FtSceneDev {             // passed by value as kernel argument
+    const FtInstr* instr;
+    const float* consts;
+    const FtGrid* grids;
+    const FtChild* children;
+    const float* cellCenters;   // 3 floats per cell
+    const uint32_t* cellStart;  // per grid: nCells+1 entries, absolute item indices
+    const FtItem* items;
+    const FtLight* lights;
+    const float* materials;     // 3 floats per material
+    uint32_t nInstr, nSlots, nLights, fastPath;
+    float bg[3];
+    float pad;
+};
+
+struct FtStatsDev {
+    unsigned long long rays_primary, rays_shadow, rays_ext, hits_primary, hits_shadow, sdf_evals, flags, pad;
+};
+
+#define FT_STEP_CAP (1u << 20)  // the reference has no cap (SdfForm.fs:93-104); see DESIGN.md "NaN / step cap"
+#define FT_MAX_SLOTS 48

@@ -1,0 +1,34 @@
+// ft_kernels.h — kernel argument block and host-callable launchers (implemented in kernels.hip / launch.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/fraytracer_hip.h"
+#include "ft_device.h"
+
+#define FT_BLOCK 256          // 4 waves; every wave is an independent persistent worker
+
+struct FtRenderArgs {
+    FtSceneDev S;
+    float cam[12];            // Position, Forward, UpScaled, RightScaled (Camera.fs:16-22)
+    int32_t W, H, x0, nCols;
+    uint32_t stripeW, stripeRanks, stripeRank, mode;    // mode 0: Image.render pixels, 1: explicit ray buffer
+    float maxSize, eps, length, pad0;
+    const ft_ray* rays;
+    float* out;
+    uint32_t* counter;        // global job cursor (zeroed before every launch)
+    FtStatsDev* stats;
+    uint32_t nJobs, chunk, tilesY, pad1;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st);
+hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
+                                 unsigned blocks, size_t ldsBytes, hipStream_t st);
+hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st);
+hipError_t ft_trace_occupancy(size_t ldsBytes, int* blocksPerCU);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,464 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the FrayTracer hot path.
+//
+// One lane = one ray at a time.  A workgroup is four independent persistent waves; every wave
+// runs a per-lane state machine whose only expensive step is "evaluate the scene SDF at my
+// query point":
+//     MARCH (SdfForm.tryTrace, SdfForm.fs:93-104)  ->  NX,NY,NZ,NC (SdfForm.normal, :106-115)
+//     -> LIGHTS (SdfScene.trace, SdfScene.fs:12-26) -> SHADOW march per light (SdfLight.fs:10-20,
+//     26-41) -> write FColor (SdfScene.fs:28) -> IDLE -> refill.
+// Lanes whose ray finished are refilled from a wave-local chunk of jobs (one global atomic per
+// chunk), so secondary (shadow) rays never touch HBM and all 64 lanes keep evaluating — this is
+// the "persistent-threads compaction" of the design (DESIGN.md "Kernel").
+//
+// The arithmetic is IEEE float32 in the reference's operation order; build with
+// -ffp-contract=off (no implicit FMA) and hipcc's default correctly rounded sqrt/divide.
+#include <hip/hip_runtime.h>
+
+#include "../../include/fraytracer_hip.h"
+#include "ft_device.h"
+#include "ft_kernels.h"
+#include "ft_math.h"
+
+// ------------------------------------------------------------------------------------------------
+// primitives (SdfForm.fs:125-268).  `c` points at the primitive's constant-pool record; when the
+// index is wave-uniform the compiler turns these into scalar loads.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f3 ld3(const float* __restrict__ c) { return mk3(c[0], c[1], c[2]); }
+
+__device__ __forceinline__ float prim_sphere(const float* __restrict__ c, f3 p) {
+    return ft_distance(ld3(c), p) - c[3];                              // SdfForm.fs:129
+}
+
+__device__ __forceinline__ float prim_capsule(const float* __restrict__ c, f3 p) {
+    const f3 diff = p - ld3(c);                                        // :153
+    const f3 dir = ld3(c + 4);
+    const float t = ft_dot(diff, ld3(c + 8));                          // :154
+    f3 w = dir * t;                                                    // :160
+    if (t >= 1.0f) w = dir;                                            // :157-158
+    if (t <= 0.0f) w = mk3(0.0f, 0.0f, 0.0f);                          // :155-156  (diff - 0 == diff)
+    return ft_distance(diff, w) - c[3];                                // :164
+}
+
+__device__ __forceinline__ float prim_torus(const float* __restrict__ c, f3 p) {
+    const f3 n = ld3(c + 4);
+    const float distanceToPlane = ft_dot(p, n) + c[8];                 // :190
+    const float distanceToCenter = ft_distance(ld3(c), p - (distanceToPlane * n));   // :191
+    const float distanceToCircle = distanceToCenter - c[3];            // :192
+    return sqrtf(distanceToPlane * distanceToPlane + distanceToCircle * distanceToCircle) - c[7];   // :194
+}
+
+__device__ __forceinline__ float prim_triangle(const float* __restrict__ c, f3 p) {
+    const f3 p1 = p - ld3(c), p2 = p - ld3(c + 4), p3 = p - ld3(c + 8);   // :228-230
+    float distance;
+    const int s = ft_sign_i(ft_dot(ld3(c + 40), p1)) + ft_sign_i(ft_dot(ld3(c + 44), p2)) + ft_sign_i(ft_dot(ld3(c + 48), p3));
+    if (s < 2) {                                                       // :235-237
+        const f3 v21 = ld3(c + 12), v32 = ld3(c + 16), v13 = ld3(c + 20);
+        const float d21 = ft_distance2(p1, v21 * ft_clamp01(ft_dot(ld3(c + 24), p1)));   // :240
+        const float d32 = ft_distance2(p2, v32 * ft_clamp01(ft_dot(ld3(c + 28), p2)));   // :241
+        const float d13 = ft_distance2(p3, v13 * ft_clamp01(ft_dot(ld3(c + 32), p3)));   // :242
+        distance = sqrtf(ft_min(d13, ft_min(d32, d21)));               // :243-244
+    } else {
+        distance = fabsf(ft_dot(ld3(c + 36), p1));                     // :247-248
+    }
+    return distance - c[3];                                            // :250
+}
+
+__device__ __forceinline__ float prim_box(const float* __restrict__ c, f3 p) {   // EXTENSION
+    const f3 d = p - ld3(c);
+    const f3 q = mk3(fabsf(d.x) - c[4], fabsf(d.y) - c[5], fabsf(d.z) - c[6]);
+    const f3 qp = mk3(ft_max(q.x, 0.0f), ft_max(q.y, 0.0f), ft_max(q.z, 0.0f));
+    return ft_length(qp) + ft_min(ft_max(q.x, ft_max(q.y, q.z)), 0.0f);
+}
+
+__device__ __forceinline__ float prim_eval(uint32_t type, const float* __restrict__ c, f3 p) {
+    switch (type) {
+        case FT_PR_SPHERE: return prim_sphere(c, p);
+        case FT_PR_CAPSULE: return prim_capsule(c, p);
+        case FT_PR_TORUS: return prim_torus(c, p);
+        case FT_PR_TRIANGLE: return prim_triangle(c, p);
+        default: return prim_box(c, p);
+    }
+}
+
+__device__ __forceinline__ uint32_t prim_stride(uint32_t type) {
+    switch (type) {
+        case FT_PR_SPHERE: return FT_STRIDE_SPHERE;
+        case FT_PR_CAPSULE: return FT_STRIDE_CAPSULE;
+        case FT_PR_TORUS: return FT_STRIDE_TORUS;
+        case FT_PR_TRIANGLE: return FT_STRIDE_TRIANGLE;
+        default: return FT_STRIDE_BOX;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// union through the uniform grid: SdfBoundary.fs:276-282 lookup, SdfForm.fs:22-34 fold, with the
+// argmin of SdfObject.fs:27-46 tracked in the same sweep (same grid, same tests, strict '<').
+// Per-lane candidate list; lanes of a wave are neighbouring pixels and mostly share the cell.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid& g, const f3 p,
+                                           const float* __restrict__ sd, const uint32_t* __restrict__ sl,
+                                           float& outD, uint32_t& outLeaf) {
+    const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
+    const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
+    const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
+    const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
+    const uint32_t cell = g.cellBase + (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz);
+    const float* ctr = S.cellCenters + 3u * cell;
+    const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
+    uint32_t i = S.cellStart[cell];
+    const uint32_t end = S.cellStart[cell + 1];
+    const FtChild* kids = S.children + g.childBase;
+
+    float mn; uint32_t leaf;
+    {                                                                  // Items.[0]  (SdfForm.fs:26)
+        const FtChild& k = kids[S.items[i].child];
+        if (k.type == FT_PR_SLOT) { mn = sd[k.data * FT_BLOCK]; leaf = sl[k.data * FT_BLOCK]; }
+        else { mn = prim_eval(k.type, S.consts + k.data, p); leaf = k.mat; }
+    }
+    for (++i; i < end; ++i) {                                          // SdfForm.fs:27
+        const FtItem it = S.items[i];
+        if (mn > it.lowerBound - distanceToCenter) {                   // :30
+            const FtChild& k = kids[it.child];
+            if (mn > ft_distance(mk3(k.bc[0], k.bc[1], k.bc[2]), p) - k.br) {   // :31 getMinDistance
+                float d; uint32_t l;
+                if (k.type == FT_PR_SLOT) { d = sd[k.data * FT_BLOCK]; l = sl[k.data * FT_BLOCK]; }
+                else { d = prim_eval(k.type, S.consts + k.data, p); l = k.mat; }
+                if (d < mn) leaf = l;                                  // SdfObject.fs:41-43
+                mn = ft_min(mn, d);                                    // SdfForm.fs:33
+            }
+        }
+    }
+    outD = mn; outLeaf = leaf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene SDF: wave-uniform program over per-lane value slots kept in LDS (slot s of thread t at
+// word s*FT_BLOCK + t: conflict-free).  Returns scene.Object.Form.Distance(p) and the material
+// the reference's material closure would pick at p.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
+                                        float& outD, uint32_t& outLeaf) {
+    for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
+        const FtInstr in = S.instr[pc];
+        float* dst = sd + in.dst * FT_BLOCK;
+        switch (in.op) {
+        case FT_OP_PRIM:
+            *dst = prim_eval(in.type, S.consts + in.data, p);
+            break;
+        case FT_OP_SETLEAF:
+            sl[in.dst * FT_BLOCK] = in.aux;
+            break;
+        case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
+            float sum = (in.flags & 1u) ? 0.0f : *dst;
+            const float* c = S.consts + in.data;
+            const uint32_t stride = prim_stride(in.type);
+            for (uint32_t i = 0; i < in.count; ++i)
+                sum = sum + ft_exp(in.f0 * prim_eval(in.type, c + i * stride, p));
+            *dst = sum;
+            break;
+        }
+        case FT_OP_SMOOTH_ADD: {
+            const float sum = (in.flags & 1u) ? 0.0f : *dst;
+            *dst = sum + ft_exp(in.f0 * sd[in.src * FT_BLOCK]);
+            break;
+        }
+        case FT_OP_SMOOTH_FIN:                                         // SdfForm.fs:82
+            *dst = -ft_log(*dst) * in.f0;
+            break;
+        case FT_OP_SUBTRACT:                                           // SdfForm.fs:46-47
+            *dst = ft_max(-(sd[in.src * FT_BLOCK]), *dst);
+            break;
+        case FT_OP_ISECT_RUN: {                                        // SdfForm.fs:60-63
+            float mx = *dst;
+            const float* c = S.consts + in.data;
+            const float* bd = S.consts + in.aux;
+            const uint32_t stride = prim_stride(in.type);
+            for (uint32_t i = 0; i < in.count; ++i) {
+                const float v = prim_eval(in.type, c + i * stride, p);
+                if (mx < ft_distance(ld3(bd + 4 * i), p) + bd[4 * i + 3]) mx = ft_max(mx, v);
+            }
+            *dst = mx;
+            break;
+        }
+        case FT_OP_ISECT_APPLY: {
+            const float* bd = S.consts + in.aux;
+            const float mx = *dst;
+            if (mx < ft_distance(ld3(bd), p) + bd[3]) *dst = ft_max(mx, sd[in.src * FT_BLOCK]);
+            break;
+        }
+        case FT_OP_UNION: {
+            float d; uint32_t l;
+            eval_union(S, S.grids[in.aux], p, sd, sl, d, l);
+            *dst = d; sl[in.dst * FT_BLOCK] = l;
+            break;
+        }
+        default: break;
+        }
+    }
+    outD = sd[0];
+    outLeaf = sl[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// render / trace kernel
+// ------------------------------------------------------------------------------------------------
+enum : uint32_t { PH_IDLE = 0, PH_DONE, PH_MARCH, PH_NX, PH_NY, PH_NZ, PH_NC, PH_LIGHTS, PH_SHADOW };
+
+struct LaneState {
+    uint32_t phase, job, steps, lidx, leaf, outIdx;
+    f3 o, dir;            // current ray (primary, then the shadow ray of light lidx)
+    float len, eps;
+    f3 hp;                // result.Ray.Origin after Ray.move -eps (SdfObject.fs:73) = result.Position
+    f3 nrm;               // NX..NZ: the three probes; afterwards the normal
+    f3 lacc;              // lightColor (SdfScene.fs:12)
+    f3 lint;              // intensity the current light adds when unshadowed
+    float lcos;
+    uint32_t cEvals, cShadow, cHitP, cHitS, cPrimary, cFlags;
+};
+
+__device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx, f3 c) {
+    float* o = out + 3ull * idx;
+    o[0] = c.x; o[1] = c.y; o[2] = c.z;
+}
+
+// advance a lane until it needs an SDF evaluation (or is idle): everything in SdfScene.trace that
+// is not a Distance call.
+__device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
+    const float piInv = 1.0f / 3.14159274101257324f;                   // Math.fs:28-30
+    for (;;) {
+        if (s.phase == PH_MARCH) {
+            if (s.len <= 0.0f) {                                       // SdfForm.fs:94 -> SdfScene.fs:10
+                write_rgb(a.out, s.outIdx, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
+                s.phase = PH_IDLE;
+            }
+            return;
+        }
+        if (s.phase == PH_SHADOW) {
+            if (s.len <= 0.0f) {                                       // shadow ray missed: light arrives
+                s.lacc = s.lacc + s.lint * s.lcos;                     // SdfScene.fs:23
+                s.lidx += 1; s.phase = PH_LIGHTS;
+                continue;
+            }
+            return;
+        }
+        if (s.phase == PH_LIGHTS) {
+            if (s.lidx >= a.S.nLights) {                               // SdfScene.fs:28
+                const float* m = a.S.materials + 3u * s.leaf;
+                const f3 color = mk3(m[0], m[1], m[2]);
+                write_rgb(a.out, s.outIdx, color * (s.lacc * piInv));
+                s.phase = PH_IDLE;
+                return;
+            }
+            const FtLight L = a.S.lights[s.lidx];
+            const f3 lv = mk3(L.v[0], L.v[1], L.v[2]);
+            const f3 lc = mk3(L.color[0], L.color[1], L.color[2]);
+            f3 ldir;
+            if (L.type == FT_LIGHT_DIRECTIONAL) ldir = lv;             // SdfLight.fs:9
+            else ldir = ft_normalize(lv - s.hp);                       // SdfLight.fs:25
+            const float lightCos = ft_dot(s.nrm, ldir);                // SdfScene.fs:15
+            if (lightCos > 0.0f) {                                     // SdfScene.fs:17
+                s.lcos = lightCos;
+                s.o = s.hp;
+                if (L.type == FT_LIGHT_DIRECTIONAL) {                  // SdfLight.fs:11-16
+                    s.dir = lv; s.len = 1000.0f; s.lint = lc;
+                } else {                                               // SdfLight.fs:27-37
+                    const f3 diff = lv - s.hp;
+                    const float distance2 = ft_length2(diff);
+                    s.dir = diff / distance2;                          // not unit: reference quirk
+                    s.len = sqrtf(distance2);
+                    s.lint = lc / distance2;                           // :40
+                }
+                s.steps = 0; s.cShadow += 1;
+                s.phase = PH_SHADOW;
+                continue;
+            }
+            s.lidx += 1;
+            continue;
+        }
+        return;
+    }
+}
+
+__device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
+    if (a.mode == 1) {                                                 // explicit ray buffer (SdfScene.trace scene ray)
+        const ft_ray r = a.rays[s.job];
+        s.o = mk3(r.origin.x, r.origin.y, r.origin.z);
+        s.dir = mk3(r.direction.x, r.direction.y, r.direction.z);
+        s.len = r.length; s.eps = r.epsilon;
+        s.outIdx = s.job;
+    } else {                                                           // Image.render (Image.fs:28-34)
+        const uint32_t t = s.job >> 6, i = s.job & 63u;
+        const uint32_t tx = t / a.tilesY, ty = t - tx * a.tilesY;
+        const uint32_t cl = tx * 8u + (i >> 3), y = ty * 8u + (i & 7u);
+        if (cl >= (uint32_t)a.nCols || y >= (uint32_t)a.H) { s.phase = PH_IDLE; return; }
+        const uint32_t x = (uint32_t)a.x0 + (cl / a.stripeW) * (a.stripeW * a.stripeRanks) + a.stripeRank * a.stripeW + cl % a.stripeW;
+        const float px = (float)x / a.maxSize, py = (float)y / a.maxSize;     // Image.fs:20-23
+        const f3 fw = mk3(a.cam[3], a.cam[4], a.cam[5]), up = mk3(a.cam[6], a.cam[7], a.cam[8]), rt = mk3(a.cam[9], a.cam[10], a.cam[11]);
+        s.o = mk3(a.cam[0], a.cam[1], a.cam[2]);
+        s.dir = ft_normalize(fw + (px - 0.5f) * rt + (py - 0.5f) * up);       // Camera.fs:48-51
+        s.len = a.length; s.eps = a.eps;
+        s.outIdx = cl * (uint32_t)a.H + y;
+    }
+    s.steps = 0; s.cPrimary += 1;
+    s.phase = PH_MARCH;
+    settle(a, s);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
+    unsigned long long x = v;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+extern __shared__ float ft_lds[];
+
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtRenderArgs a) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    float* sd = ft_lds + tid;
+    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + a.S.nSlots * FT_BLOCK) + tid;
+
+    uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
+    bool exhausted = false;
+    LaneState s;
+    s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
+    s.o = s.dir = s.hp = s.nrm = s.lacc = s.lint = mk3(0, 0, 0);
+    s.len = 0; s.eps = 0; s.lcos = 0;
+    s.cEvals = s.cShadow = s.cHitP = s.cHitS = s.cPrimary = s.cFlags = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk ------------------------------------------
+        for (int round = 0; round < 3; ++round) {
+            const unsigned long long idle = __ballot(s.phase == PH_IDLE);
+            if (idle == 0ull) break;
+            if (chunkNext == chunkEnd) {
+                if (exhausted) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.counter, a.chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= a.nJobs) { exhausted = true; break; }
+                chunkNext = base;
+                chunkEnd = (a.nJobs - base < a.chunk) ? a.nJobs : base + a.chunk;
+            }
+            const uint32_t avail = chunkEnd - chunkNext;
+            const uint32_t nIdle = (uint32_t)__popcll(idle);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (s.phase == PH_IDLE && rank < avail) { s.job = chunkNext + rank; start_job(a, s); }
+            chunkNext += (nIdle < avail) ? nIdle : avail;
+        }
+        if (s.phase == PH_IDLE && exhausted && chunkNext == chunkEnd) s.phase = PH_DONE;
+        if (__ballot(s.phase != PH_DONE) == 0ull) break;
+
+        // ---- one scene-SDF evaluation per active lane -----------------------------------------
+        const bool active = s.phase >= PH_MARCH && s.phase != PH_LIGHTS;
+        if (active) {
+            f3 q = s.o;
+            if (s.phase >= PH_NX && s.phase <= PH_NC) {                // SdfForm.fs:106-115
+                const f3 base = s.o + s.dir * (-s.eps);                // Ray.get (-eps)
+                const float h = s.eps * 0.125f;
+                q = base;
+                if (s.phase == PH_NX) q.x = base.x + h;
+                if (s.phase == PH_NY) q.y = base.y + h;
+                if (s.phase == PH_NZ) q.z = base.z + h;
+            }
+            float d; uint32_t leaf;
+            ft_eval(a.S, q, sd, sl, d, leaf);
+            s.cEvals += 1;
+
+            switch (s.phase) {
+            case PH_MARCH:
+            case PH_SHADOW: {
+                const bool primary = s.phase == PH_MARCH;
+                bool miss = false;
+                if (d != d) { s.cFlags |= 1u; miss = true; }           // reference would never terminate
+                else if (d < s.eps) {                                  // SdfForm.fs:98
+                    if (primary) { s.cHitP += 1; s.leaf = leaf; s.phase = PH_NX; }
+                    else { s.cHitS += 1; s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
+                } else {
+                    s.o = s.o + s.dir * d;                             // Ray.move (Ray.fs:9-13)
+                    s.len = s.len - d;
+                    s.steps += 1;
+                    if (s.steps >= FT_STEP_CAP) { s.cFlags |= 4u; miss = true; }
+                }
+                if (miss) s.len = -1.0f;                               // resolved as a miss by settle()
+                break;
+            }
+            case PH_NX: s.nrm.x = d; s.phase = PH_NY; break;
+            case PH_NY: s.nrm.y = d; s.phase = PH_NZ; break;
+            case PH_NZ: s.nrm.z = d; s.phase = PH_NC; break;
+            case PH_NC: {
+                s.nrm = ft_normalize(s.nrm - splat3(d));               // SdfForm.fs:107-112
+                s.hp = s.o + s.dir * (-s.eps);                         // SdfObject.fs:73
+                s.lacc = mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]);         // SdfScene.fs:12
+                s.lidx = 0;
+                s.phase = PH_LIGHTS;
+                break;
+            }
+            default: break;
+            }
+            settle(a, s);
+        }
+    }
+
+    // ---- statistics -------------------------------------------------------------------------
+    const unsigned long long e = wave_sum(s.cEvals), sh = wave_sum(s.cShadow), hp = wave_sum(s.cHitP),
+                             hs = wave_sum(s.cHitS), pr = wave_sum(s.cPrimary);
+    const unsigned long long fl = __ballot((s.cFlags & 1u) != 0) ? 1ull : 0ull;
+    const unsigned long long fc = __ballot((s.cFlags & 4u) != 0) ? 4ull : 0ull;
+    if (lane == 0) {
+        atomicAdd(&a.stats->sdf_evals, e);
+        atomicAdd(&a.stats->rays_shadow, sh);
+        atomicAdd(&a.stats->hits_primary, hp);
+        atomicAdd(&a.stats->hits_shadow, hs);
+        atomicAdd(&a.stats->rays_primary, pr);
+        if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
+    }
+}
+
+// scene.Object.Form.Distance at explicit points (test / diagnostic entry)
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
+                                                                            long long n, float* __restrict__ outD, int* __restrict__ outM) {
+    const uint32_t tid = threadIdx.x;
+    float* sd = ft_lds + tid;
+    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + S.nSlots * FT_BLOCK) + tid;
+    for (long long i = (long long)blockIdx.x * FT_BLOCK + tid; i < n; i += (long long)gridDim.x * FT_BLOCK) {
+        float d; uint32_t leaf;
+        ft_eval(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, d, leaf);
+        outD[i] = d;
+        if (outM) outM[i] = (int)leaf;
+    }
+}
+
+// device math primitives, for bit-parity tests against the oracle
+extern "C" __global__ void ft_math_kernel(int op, const float* __restrict__ x, const float* __restrict__ y, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float r;
+        switch (op) {
+            case 0: r = ft_exp(v); break;
+            case 1: r = ft_log(v); break;
+            case 2: r = sqrtf(v); break;
+            default: r = v / y[i]; break;
+        }
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers (kept in this translation unit so the C ABI file is plain C++)
+// ------------------------------------------------------------------------------------------------
+extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
+    hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
+                                            unsigned blocks, size_t ldsBytes, hipStream_t st) {
+    hipLaunchKernelGGL(ft_eval_points_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *S, pts, n, outD, outM);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(ft_math_kernel, dim3(1024), dim3(256), 0, st, op, x, y, n, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_trace_occupancy(size_t ldsBytes, int* blocksPerCU) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel, FT_BLOCK, ldsBytes);
+}

@@ -1,0 +1,134 @@
+// multi.cpp — single-process multi-GPU render: column stripes per device + ONE ncclGather (RCCL
+// over xGMI) of the per-device FColor slabs to the first device.
+//
+// Pixels are independent (immutable scene, Image.fs:28-35), so the only communication is the
+// collection of the finished slabs.  Columns are dealt in stripes of `stripe_width` so that the
+// expensive centre of the image is spread over all devices; because the output is column-major
+// (Array2D.fs:30-38) every stripe is one contiguous run of stripe_width*height*3 floats in both
+// the gathered buffer and the final image, so de-interleaving is part of the device->host copy.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fraytracer_hip.h"
+
+// small internal hooks exported by capi.cpp
+extern "C" {
+int ft_ctx_device_(const ft_ctx*);
+void* ft_ctx_stream_(const ft_ctx*);
+void ft_set_error_(int code, const char* msg);
+}
+
+namespace {
+
+struct CommCache {
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+};
+std::mutex g_mu;
+CommCache g_cache;
+
+int fail(int code, const std::string& m) { ft_set_error_(code, m.c_str()); return code; }
+
+bool getComms(const std::vector<int>& devs, std::vector<ncclComm_t>& out, std::string& err) {
+    if (g_cache.devices == devs) { out = g_cache.comms; return true; }
+    for (ncclComm_t c : g_cache.comms) ncclCommDestroy(c);
+    g_cache = CommCache{};
+    std::vector<ncclComm_t> comms(devs.size());
+    ncclResult_t r = ncclCommInitAll(comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) { err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return false; }
+    g_cache.devices = devs; g_cache.comms = comms;
+    out = comms;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scenes, int32_t n, const ft_camera* cam,
+                               const ft_render_params* full, float* out, ft_stats* stats) {
+    if (!ctxs || !scenes || n <= 0 || !cam || !full || !out) return fail(FT_ERR_INVALID, "bad argument");
+    const int W = full->width, H = full->height;
+    if (W <= 0 || H <= 0) return fail(FT_ERR_INVALID, "empty image");
+    const int S = full->stripe_width > 0 ? full->stripe_width : W / n;
+    if (S <= 0 || W % (S * n) != 0) return fail(FT_ERR_UNSUPPORTED, "width must be a multiple of stripe_width * n_devices");
+    const int cols = W / n;                                   // columns per device
+    const size_t slab = (size_t)cols * H * 3;                 // floats per device
+
+    std::vector<int> devs(n);
+    for (int r = 0; r < n; ++r) {
+        if (!ctxs[r] || !scenes[r]) return fail(FT_ERR_INVALID, "null context / scene");
+        devs[r] = ft_ctx_device_(ctxs[r]);
+        if (devs[r] < 0) return fail(FT_ERR_NO_DEVICE, "context has no GPU: libfraytracer_hip has no CPU fallback");
+    }
+    std::lock_guard<std::mutex> lock(g_mu);
+    std::vector<ncclComm_t> comms;
+    std::string err;
+    if (n > 1 && !getComms(devs, comms, err)) return fail(FT_ERR_COMM, err);
+
+    std::vector<float*> send(n, nullptr);
+    float* recv = nullptr;
+    std::vector<int> rcs(n, FT_OK);
+    std::vector<std::string> errs(n);
+    std::vector<ft_stats> sts(n);
+
+    auto cleanup = [&]() {
+        for (int r = 0; r < n; ++r) if (send[r]) { (void)hipSetDevice(devs[r]); (void)hipFree(send[r]); }
+        if (recv) { (void)hipSetDevice(devs[0]); (void)hipFree(recv); }
+    };
+    for (int r = 0; r < n; ++r) {
+        if (hipSetDevice(devs[r]) != hipSuccess || hipMalloc((void**)&send[r], slab * sizeof(float)) != hipSuccess) {
+            cleanup(); return fail(FT_ERR_HIP, "hipMalloc of a stripe slab failed");
+        }
+    }
+    if (n > 1) {
+        if (hipSetDevice(devs[0]) != hipSuccess || hipMalloc((void**)&recv, slab * n * sizeof(float)) != hipSuccess) {
+            cleanup(); return fail(FT_ERR_HIP, "hipMalloc of the gather buffer failed");
+        }
+    }
+
+    auto worker = [&](int r) {
+        ft_render_params p = *full;
+        p.x0 = 0; p.n_columns = cols; p.stripe_width = S; p.stripe_ranks = n; p.stripe_rank = r;
+        int rc = ft_render_device(ctxs[r], scenes[r], cam, &p, send[r]);
+        if (rc == FT_OK && n > 1) {
+            ncclResult_t nr = ncclGather(send[r], recv, slab, ncclFloat, 0, comms[r], (hipStream_t)ft_ctx_stream_(ctxs[r]));
+            if (nr != ncclSuccess) { rc = FT_ERR_COMM; errs[r] = std::string("ncclGather: ") + ncclGetErrorString(nr); }
+        } else if (rc != FT_OK) errs[r] = ft_last_error();
+        if (rc == FT_OK) { rc = ft_collect_stats(ctxs[r], &sts[r]); if (rc) errs[r] = ft_last_error(); }
+        rcs[r] = rc;
+    };
+    if (n == 1) worker(0);
+    else {
+        std::vector<std::thread> ts;
+        for (int r = 0; r < n; ++r) ts.emplace_back(worker, r);
+        for (auto& t : ts) t.join();
+    }
+    for (int r = 0; r < n; ++r) if (rcs[r] != FT_OK) { cleanup(); return fail(rcs[r], errs[r]); }
+
+    // de-interleave while copying out: stripe j of device r is columns [(j*n + r)*S, +S)
+    (void)hipSetDevice(devs[0]);
+    const float* src = n > 1 ? recv : send[0];
+    const size_t stripeFloats = (size_t)S * H * 3;
+    hipError_t he = hipSuccess;
+    for (int r = 0; r < n && he == hipSuccess; ++r)
+        for (int j = 0; j < cols / S && he == hipSuccess; ++j)
+            he = hipMemcpy(out + ((size_t)(j * n + r) * S) * H * 3, src + (size_t)r * slab + (size_t)j * stripeFloats,
+                           stripeFloats * sizeof(float), hipMemcpyDeviceToHost);
+    cleanup();
+    if (he != hipSuccess) return fail(FT_ERR_HIP, std::string("hipMemcpy of the gathered image: ") + hipGetErrorString(he));
+
+    if (stats) {
+        *stats = ft_stats{};
+        for (int r = 0; r < n; ++r) {
+            stats->rays_primary += sts[r].rays_primary; stats->rays_shadow += sts[r].rays_shadow; stats->rays_ext += sts[r].rays_ext;
+            stats->hits_primary += sts[r].hits_primary; stats->hits_shadow += sts[r].hits_shadow; stats->sdf_evals += sts[r].sdf_evals;
+            stats->flags |= sts[r].flags;
+            if (sts[r].kernel_ms > stats->kernel_ms) stats->kernel_ms = sts[r].kernel_ms;   // devices run concurrently
+        }
+    }
+    return FT_OK;
+}

@@ -1,0 +1,492 @@
+// scene.cpp — scene construction and flattening (host, float32, reference operation order).
+// Compile with -ffp-contract=off.
+#include "scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace ft {
+
+// ------------------------------------------------------------------------------------------------
+// SdfBoundary.fs:7-22 / 29-49 / 62-67
+// ------------------------------------------------------------------------------------------------
+Boundary boundaryUnion(Boundary a, Boundary b) {
+    const f3 diff = b.center - a.center;
+    const float distance = ft_length(diff);
+    if (distance + b.radius <= a.radius) return a;
+    if (distance + a.radius <= b.radius) return b;
+    const f3 dir = diff / distance;
+    const f3 pa = a.center - dir * a.radius;
+    const f3 pb = b.center + dir * b.radius;
+    return Boundary{(pa + pb) * 0.5f, ft_distance(pa, pb) * 0.5f};
+}
+
+Boundary boundaryIntersection(Boundary a, Boundary b) {
+    const f3 diff = b.center - a.center;
+    const float distance = ft_length(diff);
+    if (distance + b.radius <= a.radius) return b;
+    if (distance + a.radius <= b.radius) return a;
+    const f3 dir = diff / distance;
+    const f3 pa = a.center + dir * a.radius;
+    const f3 pb = b.center - dir * b.radius;
+    const float d2 = distance * distance;
+    const float aR2 = a.radius * a.radius;
+    const float bR2 = b.radius * b.radius;
+    // SdfBoundary.fs:48: (d2 - bR2 + aR2) is NOT squared in the reference; reproduced, not fixed.
+    const float radius = sqrtf(4.0f * d2 * aR2 - (d2 - bR2 + aR2)) / (2.0f * distance);
+    return Boundary{(pa + pb) * 0.5f, radius};
+}
+
+static inline float minDistance(const Boundary& x, f3 p) { return ft_distance(x.center, p) - x.radius; }  // :62
+static inline float maxDistance(const Boundary& x, f3 p) { return ft_distance(x.center, p) + x.radius; }  // :63
+
+// ------------------------------------------------------------------------------------------------
+// SdfBoundary.buildSpatialLookup (SdfBoundary.fs:225-274).  Quirks kept: all three counts are
+// derived from aabbSize.X (:237-239); upperBound adds half a cell diagonal once (:253).
+// ------------------------------------------------------------------------------------------------
+std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds, std::string& err) {
+    auto g = std::make_shared<HostGrid>();
+    const size_t n = bounds.size();
+    f3 aabbMin = bounds[0].center - splat3(bounds[0].radius);
+    f3 aabbMax = bounds[0].center + splat3(bounds[0].radius);
+    float sum = bounds[0].radius;
+    for (size_t i = 1; i < n; ++i) {
+        aabbMin = ft_vmin(aabbMin, bounds[i].center - splat3(bounds[i].radius));
+        aabbMax = ft_vmax(aabbMax, bounds[i].center + splat3(bounds[i].radius));
+        sum = sum + bounds[i].radius;
+    }
+    const float countSize = 1.5f * (sum / (float)(int)n);
+    const f3 aabbSize = aabbMax - aabbMin;
+    const int c = std::max(1, ft_ceiling_i(aabbSize.x / countSize));
+    if (c > 1024 || c < 1) { err = "union: grid resolution out of range (degenerate boundaries?)"; return nullptr; }
+    g->count[0] = c; g->count[1] = c; g->count[2] = c;
+    g->aabbMin = aabbMin;
+    g->cellSize = aabbSize / mk3((float)c, (float)c, (float)c);
+    g->cellSizeInv = splat3(1.0f) / g->cellSize;
+    const size_t ncells = (size_t)c * c * c;
+    if (ncells * 1 > (size_t)64 << 20) { err = "union: grid too large"; return nullptr; }
+    g->centers.resize(ncells);
+    g->cellStart.assign(ncells + 1, 0);
+    const float halfDiag = ft_length(g->cellSize * 0.5f);
+    std::vector<FtItem> cellItems;
+    for (int x = 0; x < c; ++x)
+    for (int y = 0; y < c; ++y)
+    for (int z = 0; z < c; ++z) {
+        const size_t ci = ((size_t)x * c + y) * c + z;
+        const f3 center = aabbMin + g->cellSize * 0.5f + g->cellSize * mk3((float)x, (float)y, (float)z);
+        g->centers[ci] = center;
+        float m = maxDistance(bounds[0], center);
+        for (size_t i = 1; i < n; ++i) { const float v = maxDistance(bounds[i], center); if (v < m) m = v; }
+        const float upperBound = m + halfDiag;
+        cellItems.clear();
+        for (size_t i = 0; i < n; ++i) {
+            const float lo = minDistance(bounds[i], center);
+            if (lo < upperBound) cellItems.push_back(FtItem{lo, (uint32_t)i});
+        }
+        if (cellItems.empty()) { err = "union: a lookup cell has no candidates (the reference would throw at Items.[0])"; return nullptr; }
+        // Array.sortInPlaceBy (:267-268) is unstable in .NET; ties resolved by input order here.
+        std::stable_sort(cellItems.begin(), cellItems.end(),
+                         [](const FtItem& a, const FtItem& b) { return a.lowerBound < b.lowerBound; });
+        g->cellStart[ci] = (uint32_t)g->items.size();
+        g->items.insert(g->items.end(), cellItems.begin(), cellItems.end());
+    }
+    g->cellStart[ncells] = (uint32_t)g->items.size();
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Primitives: host precomputes what each closure captures (SdfForm.fs:125-268)
+// ------------------------------------------------------------------------------------------------
+static void put3(std::vector<float>& v, f3 a, float w = 0.0f) { v.push_back(a.x); v.push_back(a.y); v.push_back(a.z); v.push_back(w); }
+
+int Builder::sphere(f3 c, float r) {                                   // SdfForm.fs:125-135
+    HostForm f; f.kind = HostForm::SPHERE;
+    put3(f.params, c, r);
+    f.boundary = Boundary{c, r};
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::capsule(f3 from, f3 to, float r) {                        // SdfForm.fs:145-170
+    HostForm f; f.kind = HostForm::CAPSULE;
+    const f3 dir = to - from;                                          // :148
+    const f3 dirInv = dir / ft_length2(dir);                           // :149, Math.fs:69
+    put3(f.params, from, r); put3(f.params, dir); put3(f.params, dirInv);
+    f.boundary = Boundary{ft_lerp(from, to, 0.5f), r + ft_distance(from, to) * 0.5f};   // :166-169
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::torus(f3 c, f3 nIn, float R, float r) {                   // SdfForm.fs:181-203
+    HostForm f; f.kind = HostForm::TORUS;
+    const f3 n = ft_normalize(nIn);                                    // :182-185
+    const float planeD = -(ft_dot(c, n));                              // :188
+    put3(f.params, c, R); put3(f.params, n, r); put3(f.params, mk3(planeD, 0, 0));
+    f.boundary = Boundary{c, R + r};                                   // :199-202
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::triangle(f3 v1, f3 v2, f3 v3, float r) {                  // SdfForm.fs:214-268
+    HostForm f; f.kind = HostForm::TRIANGLE;
+    const f3 v21 = v2 - v1, v32 = v3 - v2, v13 = v1 - v3;              // :216-220
+    const f3 v21i = v21 / ft_length2(v21), v32i = v32 / ft_length2(v32), v13i = v13 / ft_length2(v13);
+    const f3 nor = ft_normalize(ft_cross(v21, v13));                   // :222
+    const f3 n21 = ft_normalize(ft_cross(v21, nor));                   // :223
+    const f3 n32 = ft_normalize(ft_cross(v32, nor));                   // :224
+    const f3 n13 = ft_normalize(ft_cross(v13, nor));                   // :225
+    put3(f.params, v1, r); put3(f.params, v2); put3(f.params, v3);
+    put3(f.params, v21); put3(f.params, v32); put3(f.params, v13);
+    put3(f.params, v21i); put3(f.params, v32i); put3(f.params, v13i);
+    put3(f.params, nor); put3(f.params, n21); put3(f.params, n32); put3(f.params, n13);
+    // boundary = circumsphere + Radius (:252-263)
+    const float areaInv = 0.5f / ft_length2(ft_cross(v1 - v2, v2 - v3));
+    const float w1 = ft_length2(v2 - v3) * ft_dot(v1 - v2, v1 - v3) * areaInv;
+    const float w2 = ft_length2(v1 - v3) * ft_dot(v2 - v1, v2 - v3) * areaInv;
+    const float w3 = 1.0f - w1 - w2;
+    const f3 center = w1 * v1 + w2 * v2 + w3 * v3;
+    const float radius = ft_length(v21) * ft_length(v32) * ft_length(v13) / 2.0f / ft_length(ft_cross(v21, v32)) + r;
+    f.boundary = Boundary{center, radius};
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::box(f3 c, f3 half) {                                      // EXTENSION (not in the reference)
+    HostForm f; f.kind = HostForm::BOX;
+    put3(f.params, c); put3(f.params, half);
+    f.boundary = Boundary{c, ft_length(half)};
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Combinators (SdfForm.fs:14-91): a single child is returned unchanged, as in the reference.
+// ------------------------------------------------------------------------------------------------
+static bool checkKids(const Builder& b, const int* kids, int n, std::string& err) {
+    if (n <= 0 || !kids) { err = "No SdfObjects given."; return false; }
+    for (int i = 0; i < n; ++i) if (!b.okForm(kids[i])) { err = "invalid form handle"; return false; }
+    return true;
+}
+
+int Builder::formUnion(const int* kids, int n) {                       // SdfForm.fs:14-40
+    if (!checkKids(*this, kids, n, err)) return n <= 0 ? FT_ERR_EMPTY_ : FT_ERR_INVALID_;
+    if (n == 1) return kids[0];
+    HostForm f; f.kind = HostForm::UNION; f.kids.assign(kids, kids + n);
+    std::vector<Boundary> bs; for (int i = 0; i < n; ++i) bs.push_back(forms[kids[i]].boundary);
+    f.grid = buildSpatialLookup(bs, err);
+    if (!f.grid) return FT_ERR_UNSUPPORTED_;
+    Boundary acc = bs[0];                                              // Seq.reduce union (:36-39)
+    for (int i = 1; i < n; ++i) acc = boundaryUnion(acc, bs[i]);
+    f.boundary = acc;
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::formSubtract(int a, int b) {                              // SdfForm.fs:42-49
+    if (!okForm(a) || !okForm(b)) { err = "invalid form handle"; return FT_ERR_INVALID_; }
+    HostForm f; f.kind = HostForm::SUBTRACT; f.kids = {a, b};
+    f.boundary = forms[a].boundary;
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::formIntersect(const int* kids, int n) {                   // SdfForm.fs:51-67
+    if (!checkKids(*this, kids, n, err)) return n <= 0 ? FT_ERR_EMPTY_ : FT_ERR_INVALID_;
+    if (n == 1) return kids[0];
+    HostForm f; f.kind = HostForm::INTERSECT; f.kids.assign(kids, kids + n);
+    Boundary acc = forms[kids[0]].boundary;                            // Seq.reduce intersection (:66)
+    for (int i = 1; i < n; ++i) acc = boundaryIntersection(acc, forms[kids[i]].boundary);
+    f.boundary = acc;
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+int Builder::formUnionSmooth(float strength, const int* kids, int n) { // SdfForm.fs:69-91
+    if (!checkKids(*this, kids, n, err)) return n <= 0 ? FT_ERR_EMPTY_ : FT_ERR_INVALID_;
+    if (n == 1) return kids[0];
+    HostForm f; f.kind = HostForm::SMOOTH; f.kids.assign(kids, kids + n); f.strength = strength;
+    Boundary acc = forms[kids[0]].boundary;                            // :87-90
+    for (int i = 1; i < n; ++i) acc = boundaryUnion(acc, forms[kids[i]].boundary);
+    f.boundary = acc;
+    forms.push_back(f); return (int)forms.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SdfMaterial.fs:4-7, SdfObject.fs:6-64, SdfLight.fs:6-42
+// ------------------------------------------------------------------------------------------------
+int Builder::materialSolid(f3 rgb) { materials.push_back(rgb); return (int)materials.size() - 1; }
+
+int Builder::objectCreate(int material, int form) {                    // SdfObject.fs:6-10
+    if (material < 0 || (size_t)material >= materials.size() || !okForm(form)) { err = "invalid handle"; return FT_ERR_INVALID_; }
+    HostObject o; o.kind = HostObject::CREATE; o.material = material; o.form = form;
+    objects.push_back(o); return (int)objects.size() - 1;
+}
+
+int Builder::objectUnion(const int* objs, int n) {                     // SdfObject.fs:12-48
+    if (n <= 0 || !objs) { err = "No SdfObjects given."; return FT_ERR_EMPTY_; }
+    for (int i = 0; i < n; ++i) if (!okObject(objs[i])) { err = "invalid object handle"; return FT_ERR_INVALID_; }
+    if (n == 1) return objs[0];
+    std::vector<int> fs; for (int i = 0; i < n; ++i) fs.push_back(objects[objs[i]].form);
+    // Form = SdfForm.union of the children's forms (:16-19).  The material closure builds a second
+    // lookup from the same boundaries (:26); it is identical, so one grid serves both.
+    const int form = formUnion(fs.data(), n);
+    if (form < 0) return form;
+    HostObject o; o.kind = HostObject::UNION; o.form = form; o.kidObjects.assign(objs, objs + n);
+    objects.push_back(o); return (int)objects.size() - 1;
+}
+
+int Builder::objectSubtract(int obj, int form) {                       // SdfObject.fs:50-54
+    if (!okObject(obj) || !okForm(form)) { err = "invalid handle"; return FT_ERR_INVALID_; }
+    const int f = formSubtract(objects[obj].form, form);
+    if (f < 0) return f;
+    HostObject o; o.kind = HostObject::SUBTRACT; o.form = f; o.inner = obj; o.forms = {form};
+    objects.push_back(o); return (int)objects.size() - 1;
+}
+
+int Builder::objectIntersect(int obj, const int* fs, int n) {          // SdfObject.fs:56-64
+    if (!okObject(obj)) { err = "invalid object handle"; return FT_ERR_INVALID_; }
+    std::vector<int> all; all.push_back(objects[obj].form);
+    for (int i = 0; i < n; ++i) { if (!okForm(fs[i])) { err = "invalid form handle"; return FT_ERR_INVALID_; } all.push_back(fs[i]); }
+    const int f = formIntersect(all.data(), (int)all.size());
+    if (f < 0) return f;
+    HostObject o; o.kind = HostObject::INTERSECT; o.form = f; o.inner = obj; o.forms.assign(fs, fs + n);
+    objects.push_back(o); return (int)objects.size() - 1;
+}
+
+int Builder::lightDirectional(f3 dir, f3 rgb) {                        // SdfLight.fs:6-21
+    HostLight l{}; l.dev.type = FT_LIGHT_DIRECTIONAL;
+    const f3 d = ft_normalize(neg3(dir));                              // :7
+    l.dev.v[0] = d.x; l.dev.v[1] = d.y; l.dev.v[2] = d.z;
+    l.dev.color[0] = rgb.x; l.dev.color[1] = rgb.y; l.dev.color[2] = rgb.z;
+    lights.push_back(l); return (int)lights.size() - 1;
+}
+
+int Builder::lightPoint(f3 pos, f3 rgb) {                              // SdfLight.fs:23-42
+    HostLight l{}; l.dev.type = FT_LIGHT_POINT;
+    l.dev.v[0] = pos.x; l.dev.v[1] = pos.y; l.dev.v[2] = pos.z;
+    l.dev.color[0] = rgb.x; l.dev.color[1] = rgb.y; l.dev.color[2] = rgb.z;
+    lights.push_back(l); return (int)lights.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flattening
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Flattener {
+    const Builder& b;
+    FlatScene& out;
+    std::string& err;
+    uint32_t maxSlot = 0;
+    bool failed = false;
+
+    Flattener(const Builder& b_, FlatScene& o, std::string& e) : b(b_), out(o), err(e) {}
+
+    bool fail(const std::string& m) { if (!failed) err = m; failed = true; return false; }
+    void useSlot(uint32_t s) { if (s > maxSlot) maxSlot = s; }
+
+    static uint32_t primType(HostForm::Kind k) {
+        switch (k) {
+            case HostForm::SPHERE: return FT_PR_SPHERE; case HostForm::CAPSULE: return FT_PR_CAPSULE;
+            case HostForm::TORUS: return FT_PR_TORUS; case HostForm::TRIANGLE: return FT_PR_TRIANGLE;
+            default: return FT_PR_BOX;
+        }
+    }
+    uint32_t addConsts(const std::vector<float>& p) {
+        const uint32_t at = (uint32_t)out.consts.size();
+        out.consts.insert(out.consts.end(), p.begin(), p.end());
+        return at;
+    }
+    uint32_t addBoundary(const Boundary& bd) {
+        const uint32_t at = (uint32_t)out.consts.size();
+        out.consts.push_back(bd.center.x); out.consts.push_back(bd.center.y); out.consts.push_back(bd.center.z); out.consts.push_back(bd.radius);
+        return at;
+    }
+    FtInstr mk(uint32_t op, uint32_t dst) { FtInstr i{}; i.op = op; i.dst = dst; return i; }
+
+    // length of the run of consecutive primitives of one type starting at kids[i]
+    size_t runLength(const std::vector<int>& kids, size_t i) const {
+        const HostForm& f0 = b.forms[kids[i]];
+        if (!f0.isPrim()) return 0;
+        size_t j = i + 1;
+        while (j < kids.size() && b.forms[kids[j]].kind == f0.kind) ++j;
+        return j - i;
+    }
+
+    bool emitForm(int h, uint32_t dst) {
+        if (failed) return false;
+        if (dst >= FT_MAX_SLOTS) return fail("scene nests deeper than FT_MAX_SLOTS value slots");
+        useSlot(dst);
+        const HostForm& f = b.forms[h];
+        switch (f.kind) {
+        case HostForm::SPHERE: case HostForm::CAPSULE: case HostForm::TORUS: case HostForm::TRIANGLE: case HostForm::BOX: {
+            FtInstr i = mk(FT_OP_PRIM, dst); i.type = primType(f.kind); i.data = addConsts(f.params); i.count = 1;
+            out.instr.push_back(i);
+            return true;
+        }
+        case HostForm::SUBTRACT: {                                     // Max(-(b), a): a first, then b
+            if (!emitForm(f.kids[0], dst) || !emitForm(f.kids[1], dst + 1)) return false;
+            FtInstr i = mk(FT_OP_SUBTRACT, dst); i.src = dst + 1;
+            out.instr.push_back(i);
+            return true;
+        }
+        case HostForm::INTERSECT: return emitIntersect(f.kids, dst, -1);
+        case HostForm::SMOOTH: {
+            const float strengthInverse = -1.0f / f.strength;          // SdfForm.fs:75
+            bool first = true;
+            for (size_t k = 0; k < f.kids.size();) {
+                const size_t run = runLength(f.kids, k);
+                if (run > 0) {
+                    const HostForm& p0 = b.forms[f.kids[k]];
+                    FtInstr i = mk(FT_OP_SMOOTH_RUN, dst); i.type = primType(p0.kind); i.count = (uint32_t)run;
+                    i.data = (uint32_t)out.consts.size(); i.f0 = strengthInverse; i.flags = first ? 1u : 0u;
+                    for (size_t j = 0; j < run; ++j) addConsts(b.forms[f.kids[k + j]].params);
+                    out.instr.push_back(i);
+                    k += run;
+                } else {
+                    if (!emitForm(f.kids[k], dst + 1)) return false;
+                    FtInstr i = mk(FT_OP_SMOOTH_ADD, dst); i.src = dst + 1; i.f0 = strengthInverse; i.flags = first ? 1u : 0u;
+                    out.instr.push_back(i);
+                    k += 1;
+                }
+                first = false;
+            }
+            FtInstr i = mk(FT_OP_SMOOTH_FIN, dst); i.f0 = f.strength;
+            out.instr.push_back(i);
+            return true;
+        }
+        case HostForm::UNION: {
+            std::vector<int> objs(f.kids.size(), -1);
+            return emitUnion(f, objs, dst);
+        }
+        }
+        return fail("unknown form kind");
+    }
+
+    // intersect: kids[0] evaluated unconditionally into dst (firstObject >= 0: it is an object whose
+    // material is kept, SdfObject.fs:56-64), every further child behind the getMaxDistance test.
+    bool emitIntersect(const std::vector<int>& kids, uint32_t dst, int firstObject) {
+        if (firstObject >= 0) { if (!emitObject(firstObject, dst)) return false; }
+        else if (!emitForm(kids[0], dst)) return false;
+        for (size_t k = 1; k < kids.size();) {
+            const size_t run = runLength(kids, k);
+            if (run > 0) {
+                const HostForm& p0 = b.forms[kids[k]];
+                FtInstr i = mk(FT_OP_ISECT_RUN, dst); i.type = primType(p0.kind); i.count = (uint32_t)run;
+                i.data = (uint32_t)out.consts.size();
+                for (size_t j = 0; j < run; ++j) addConsts(b.forms[kids[k + j]].params);
+                i.aux = (uint32_t)out.consts.size();
+                for (size_t j = 0; j < run; ++j) addBoundary(b.forms[kids[k + j]].boundary);
+                out.instr.push_back(i);
+                k += run;
+            } else {
+                if (!emitForm(kids[k], dst + 1)) return false;
+                FtInstr i = mk(FT_OP_ISECT_APPLY, dst); i.src = dst + 1; i.aux = addBoundary(b.forms[kids[k]].boundary);
+                out.instr.push_back(i);
+                k += 1;
+            }
+        }
+        return true;
+    }
+
+    // union over f.kids; objs[i] >= 0 when child i is an SdfObject (material tracking), else -1.
+    // Primitive children go straight into the child table; any other child is evaluated first,
+    // unconditionally, into its own slot (evaluation has no side effects, so applying the
+    // reference's pruning tests to the stored value gives the reference's result).
+    bool emitUnion(const HostForm& f, const std::vector<int>& objs, uint32_t dst) {
+        const uint32_t childBase = (uint32_t)out.children.size();
+        out.children.resize(childBase + f.kids.size());
+        uint32_t nextSlot = dst + 1;
+        for (size_t k = 0; k < f.kids.size(); ++k) {
+            const HostForm& kf = b.forms[f.kids[k]];
+            FtChild c{};
+            c.bc[0] = kf.boundary.center.x; c.bc[1] = kf.boundary.center.y; c.bc[2] = kf.boundary.center.z; c.br = kf.boundary.radius;
+            const int ko = objs[k];
+            const bool solidPrim = kf.isPrim() && (ko < 0 || b.objects[ko].kind == HostObject::CREATE);
+            if (solidPrim) {
+                c.type = primType(kf.kind); c.data = addConsts(kf.params);
+                c.mat = ko >= 0 ? (uint32_t)b.objects[ko].material : 0u;
+            } else {
+                if (nextSlot >= FT_MAX_SLOTS) return fail("union has more combinator children than FT_MAX_SLOTS value slots");
+                if (ko >= 0 ? !emitObject(ko, nextSlot) : !emitForm(f.kids[k], nextSlot)) return false;
+                c.type = FT_PR_SLOT; c.data = nextSlot; c.mat = 0;
+                ++nextSlot;
+            }
+            out.children[childBase + k] = c;
+        }
+        const HostGrid& g = *f.grid;
+        FtGrid dg{};
+        dg.aabbMin[0] = g.aabbMin.x; dg.aabbMin[1] = g.aabbMin.y; dg.aabbMin[2] = g.aabbMin.z;
+        dg.cellSizeInv[0] = g.cellSizeInv.x; dg.cellSizeInv[1] = g.cellSizeInv.y; dg.cellSizeInv[2] = g.cellSizeInv.z;
+        dg.count[0] = g.count[0]; dg.count[1] = g.count[1]; dg.count[2] = g.count[2];
+        dg.cellBase = (uint32_t)(out.cellCenters.size() / 3);
+        dg.childBase = childBase; dg.nChildren = (uint32_t)f.kids.size();
+        const uint32_t itemBase = (uint32_t)out.items.size();
+        for (const f3& c : g.centers) { out.cellCenters.push_back(c.x); out.cellCenters.push_back(c.y); out.cellCenters.push_back(c.z); }
+        // global CSR: cellStart has one entry per cell plus a final terminator kept at the back
+        if (!out.cellStart.empty()) out.cellStart.pop_back();
+        for (size_t ci = 0; ci + 1 < g.cellStart.size(); ++ci) out.cellStart.push_back(itemBase + g.cellStart[ci]);
+        out.items.insert(out.items.end(), g.items.begin(), g.items.end());
+        out.cellStart.push_back((uint32_t)out.items.size());
+        const uint32_t gi = (uint32_t)out.grids.size();
+        out.grids.push_back(dg);
+        FtInstr i = mk(FT_OP_UNION, dst); i.aux = gi;
+        out.instr.push_back(i);
+        useSlot(nextSlot - 1);
+        return true;
+    }
+
+    bool emitObject(int h, uint32_t dst) {
+        if (failed) return false;
+        if (dst >= FT_MAX_SLOTS) return fail("scene nests deeper than FT_MAX_SLOTS value slots");
+        useSlot(dst);
+        const HostObject& o = b.objects[h];
+        switch (o.kind) {
+        case HostObject::CREATE: {
+            if (!emitForm(o.form, dst)) return false;
+            FtInstr i = mk(FT_OP_SETLEAF, dst); i.aux = (uint32_t)o.material;
+            out.instr.push_back(i);
+            return true;
+        }
+        case HostObject::UNION: return emitUnion(b.forms[o.form], o.kidObjects, dst);
+        case HostObject::SUBTRACT: {
+            if (!emitObject(o.inner, dst) || !emitForm(o.forms[0], dst + 1)) return false;
+            FtInstr i = mk(FT_OP_SUBTRACT, dst); i.src = dst + 1;
+            out.instr.push_back(i);
+            return true;
+        }
+        case HostObject::INTERSECT: {
+            if (o.forms.empty()) return emitObject(o.inner, dst);       // SdfForm.intersect [x] = x
+            std::vector<int> kids; kids.push_back(b.objects[o.inner].form);
+            kids.insert(kids.end(), o.forms.begin(), o.forms.end());
+            return emitIntersect(kids, dst, o.inner);
+        }
+        }
+        return fail("unknown object kind");
+    }
+};
+
+}  // namespace
+
+bool flatten(const Builder& b, int object, const float bg[3], const int* lights, int nLights, FlatScene& out, std::string& err) {
+    if (!b.okObject(object)) { err = "invalid object handle"; return false; }
+    out = FlatScene{};
+    Flattener fl(b, out, err);
+    if (!fl.emitObject(object, 0)) return false;
+    out.nSlots = fl.maxSlot + 1;
+    for (int i = 0; i < nLights; ++i) {
+        if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
+        out.lights.push_back(b.lights[lights[i]].dev);
+    }
+    for (const f3& m : b.materials) { out.materials.push_back(m.x); out.materials.push_back(m.y); out.materials.push_back(m.z); }
+    out.bg[0] = bg[0]; out.bg[1] = bg[1]; out.bg[2] = bg[2];
+    if (out.cellStart.empty()) out.cellStart.push_back(0);
+    // keep every pool non-empty and padded so device-side wide loads never run off the end
+    for (int i = 0; i < 64; ++i) out.consts.push_back(0.0f);
+    return true;
+}
+
+float lensCreate(float fov) {                                          // Camera.fs:11-14
+    // F# `sin` on a float32 is evaluated in double precision and rounded (DESIGN.md assumptions)
+    return (float)sin((double)(fov * 0.5f));
+}
+
+void cameraLookAt(f3 pos, f3 lookAt, f3 up, float nearPlaneSize, f3 o[4]) {   // Camera.fs:33-42
+    const f3 forward = ft_normalize(lookAt - pos);
+    const f3 right = ft_normalize(ft_cross(up, forward));
+    o[0] = pos; o[1] = forward; o[2] = ft_cross(forward, right) * nearPlaneSize; o[3] = right * nearPlaneSize;
+}
+
+}  // namespace ft

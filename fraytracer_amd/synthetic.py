@@ -1,0 +1,156 @@
+"""Synthetic scenes of the BASELINE.json configs, built with the mirrored
+scene-composition API.  Shared conventions come from the reference's console program:
+camera src/FrayTracer.Console/Program.fs:16-22 (incl. `Lens.create 60.0f`, radians), epsilon 0.01
+and ray length 30 (Program.fs:85,93), background 0.1 (Program.fs:78), the directional light of
+Program.fs:80 and the random factories of Program.fs:32-65.
+
+The scene RNG is a portable splitmix64 (NOT System.Random), narrowed to float32 like
+Random.fs:9; pointInBall / pointOnSphere / range follow Random.fs:11, 27-40.
+"""
+import numpy as np
+
+from .api import SdfForm, SdfMaterial, SdfObject, SdfLight, SdfScene, Lens, Camera, ImageSize
+
+F = np.float32
+EPSILON = 0.01
+RAY_LENGTH = 30.0
+BACKGROUND = (0.1, 0.1, 0.1)
+
+
+class Rng:
+    def __init__(self, seed):
+        self.s = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+
+    def _next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def range_01(self):                                   # Random.fs:9
+        return F((self._next() >> 40) * (1.0 / (1 << 24)))
+
+    def range(self, lo, hi):                              # Random.fs:11
+        lo, hi = F(lo), F(hi)
+        return F(lo + F(self.range_01() * F(hi - lo)))
+
+    def _vec(self):
+        return np.array([self.range(-1, 1), self.range(-1, 1), self.range(-1, 1)], F)
+
+    def pointInBall(self, radius):                        # Random.fs:27-32
+        while True:
+            v = self._vec()
+            if F(F(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) <= F(1.0):
+                return v * F(radius)
+
+    def pointOnSphere(self, radius):                      # Random.fs:34-40
+        while True:
+            v = self._vec()
+            l = F(F(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+            if F(0.01) <= l <= F(1.0):
+                return v / np.sqrt(l) * F(radius)
+
+
+def default_camera():
+    """Program.fs:16-22"""
+    return Camera.lookAt(Position=(0.0, 0.0, -10.0), LookAt=(0.0, 0.0, 0.0), Up=(0.0, 1.0, 0.0), Lens=Lens.create(60.0))
+
+
+def program_lights():
+    """Program.fs:79-82"""
+    return [SdfLight.directional((-0.5, -1.0, 1.0), (0.5, 0.5, 0.5)),
+            SdfLight.point((-0.5, 0.0, -2.0), (10.0, 0.0, 0.0))]
+
+
+def _material(rng):                                        # Program.fs:28-30
+    return SdfMaterial.createSolid((rng.range_01(), rng.range_01(), rng.range_01()))
+
+
+def random_sphere(rng):                                    # Program.fs:32-37
+    f = SdfForm.Primitive.sphere(Center=rng.pointInBall(4.0), Radius=rng.range(0.3, 1.0))
+    return SdfObject.create(_material(rng), f)
+
+
+def random_capsule(rng):                                   # Program.fs:39-46
+    c = rng.pointInBall(4.0)
+    f = SdfForm.Primitive.capsule(From=c, To=c + rng.pointOnSphere(rng.range(0.5, 2.0)), Radius=rng.range(0.1, 0.3))
+    return SdfObject.create(_material(rng), f)
+
+
+def random_torus(rng):                                     # Program.fs:48-55
+    f = SdfForm.Primitive.torus(Center=rng.pointInBall(4.0), Normal=rng.pointOnSphere(1.0),
+                                MajorRadius=rng.range(0.1, 0.4), MinorRadius=rng.range(0.1, 0.3))
+    return SdfObject.create(_material(rng), f)
+
+
+def random_triangle(rng):                                  # Program.fs:57-65
+    v1 = rng.pointInBall(4.0)
+    f = SdfForm.Primitive.triangle(V1=v1, V2=v1 + rng.pointOnSphere(rng.range(0.2, 0.6)),
+                                   V3=v1 + rng.pointOnSphere(rng.range(0.2, 0.6)), Radius=rng.range(0.1, 0.3))
+    return SdfObject.create(_material(rng), f)
+
+
+def random_box(rng):                                       # EXTENSION
+    f = SdfForm.Primitive.box(Center=rng.pointInBall(4.0), HalfExtent=(rng.range(0.2, 0.7), rng.range(0.2, 0.7), rng.range(0.2, 0.7)))
+    return SdfObject.create(_material(rng), f)
+
+
+# ---- BASELINE.json configs -------------------------------------------------------------------------
+def config1():
+    """C1: single SDF sphere, 256x256, primary rays only."""
+    obj = SdfObject.create(SdfMaterial.createSolid((0.8, 0.8, 0.8)), SdfForm.Primitive.sphere((0.0, 0.0, 0.0), 1.0))
+    return SdfScene(obj, BACKGROUND, []), ImageSize(256, 256)
+
+
+def config2(seed=2, boxes=False, size=1024):
+    """C2: SdfObject.union of 32 leaves (16 spheres + 16 capsules; boxes=True swaps the capsules for
+    EXTENSION boxes), one directional light (its shadow rays are the secondary rays)."""
+    rng = Rng(seed)
+    objs = []
+    for _ in range(16):
+        objs.append(random_sphere(rng))
+        objs.append(random_box(rng) if boxes else random_capsule(rng))
+    lights = [SdfLight.directional((-0.5, -1.0, 1.0), (0.5, 0.5, 0.5))]
+    return SdfScene(SdfObject.union(objs), BACKGROUND, lights), ImageSize(size, size)
+
+
+def config3(seed=3, n=256, size=4096, strength=0.25):
+    """C3 (the metric's config): unionSmooth 0.25 of 256 spheres, one solid colour, directional light."""
+    rng = Rng(seed)
+    forms = [SdfForm.Primitive.sphere(Center=rng.pointInBall(4.0), Radius=rng.range(0.1, 0.5)) for _ in range(n)]
+    obj = SdfObject.create(SdfMaterial.createSolid((0.9, 0.6, 0.3)), SdfForm.unionSmooth(strength, forms))
+    lights = [SdfLight.directional((-0.5, -1.0, 1.0), (0.5, 0.5, 0.5))]
+    return SdfScene(obj, BACKGROUND, lights), ImageSize(size, size)
+
+
+def config4(seed=3):
+    """C4: the C3 scene at 8192x8192 (column-tiled over 1/2/4/8 GPUs)."""
+    scene, _ = config3(seed)
+    return scene, ImageSize(8192, 8192)
+
+
+def console_like(seed=19, n=1000, size=1000, factory=random_torus):
+    """The structure of Program.fs:67-83 — subtract(intersect(union of n random tori, sphere r3.5),
+    sphere r2.5) with the two lights — on the portable RNG (the System.Random-seeded original is
+    reproduced separately, see fraytracer_amd/dotnet_random.py)."""
+    rng = Rng(seed)
+    union = SdfObject.union([factory(rng) for _ in range(n)])
+    obj = SdfObject.subtract(
+        SdfObject.intersect(union, [SdfForm.Primitive.sphere((0.0, 0.0, 0.0), 3.5)]),
+        SdfForm.Primitive.sphere((-0.5, 1.0, -2.0), 2.5))
+    return SdfScene(obj, BACKGROUND, program_lights()), ImageSize(size, size)
+
+
+def mixed_nested(seed=7):
+    """A small scene touching every combinator and primitive, including combinator children of a
+    union (material resolution through nested object unions)."""
+    rng = Rng(seed)
+    blob = SdfObject.create(_material(rng), SdfForm.unionSmooth(0.3, [
+        SdfForm.Primitive.sphere(rng.pointInBall(2.0), rng.range(0.3, 0.8)) for _ in range(5)]))
+    inner_union = SdfObject.union([random_sphere(rng), random_torus(rng), random_capsule(rng)])
+    carved = SdfObject.subtract(random_sphere(rng), SdfForm.Primitive.sphere(rng.pointInBall(3.0), 0.8))
+    clipped = SdfObject.intersect(random_torus(rng), [SdfForm.Primitive.sphere((0, 0, 0), 4.0),
+                                                      SdfForm.union([SdfForm.Primitive.sphere((0, 0, 0), 3.9), SdfForm.Primitive.sphere((1, 0, 0), 3.9)])])
+    objs = [blob, inner_union, carved, clipped] + [random_triangle(rng) for _ in range(4)] + [random_capsule(rng) for _ in range(3)]
+    return SdfScene(SdfObject.union(objs), BACKGROUND, program_lights()), ImageSize(96, 96)

@@ -1,0 +1,174 @@
+/* fraytracer_hip.h — C ABI of libfraytracer_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for FrayTracer's per-pixel hot path.  The reference has no FFI: the
+ * seam is `SdfScene.trace : SdfScene -> Ray -> FColor` (src/FrayTracer/SdfScene.fs:7-8)
+ * driven by `Image.render` (src/FrayTracer/Image.fs:26-35), called once from
+ * src/FrayTracer.Console/Program.fs:90-93.  Because an F# scene is a record of opaque
+ * closures (src/FrayTracer/Types.fs:40-55), every scene constructor of the reference gets a
+ * native twin here; the F# layer calls the twin next to building its closure and keeps the
+ * returned handle (INTEGRATION.md shows the [<DllImport>] stubs).  The library owns
+ * flattening (boundaries, uniform grids) and all device work.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Functions return 0 / a handle
+ * >= 0 on success and a negative ft_status on failure; ft_last_error() gives the message
+ * for the calling thread.  All structs are float/int32 only, 4-byte aligned, and match the
+ * sequential layout of the F# [<Struct>] records they mirror, so they are blittable.
+ * Inputs are copied; the caller keeps ownership.  A context is not re-entrant; distinct
+ * contexts may be used from distinct threads.  There is NO CPU fallback: every render /
+ * trace entry point fails with FT_ERR_NO_DEVICE when the context has no GPU.
+ */
+#ifndef FRAYTRACER_HIP_H
+#define FRAYTRACER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FT_ABI_VERSION 1
+
+typedef enum ft_status {
+    FT_OK = 0,
+    FT_ERR_INVALID = -1,      /* bad handle / argument */
+    FT_ERR_NO_DEVICE = -2,    /* context was created without a GPU, or HIP reports none */
+    FT_ERR_HIP = -3,          /* a HIP runtime call failed (message has the HIP error string) */
+    FT_ERR_UNSUPPORTED = -4,  /* scene exceeds a documented limit (DESIGN.md "Limits") */
+    FT_ERR_EMPTY = -5,        /* empty child list: the reference throws "No SdfObjects given." */
+    FT_ERR_COMM = -6          /* RCCL failure in ft_render_multi */
+} ft_status;
+
+typedef int32_t ft_handle;                 /* index into a context-owned table; < 0 is an ft_status */
+typedef struct ft_ctx ft_ctx;
+typedef struct ft_scene ft_scene;
+
+/* ---- blittable mirrors of the reference records ------------------------------------ */
+typedef struct ft_vec3 { float x, y, z; } ft_vec3;                       /* System.Numerics.Vector3 */
+typedef struct ft_ray {                                                  /* Types.fs:9-17 (32 B) */
+    ft_vec3 origin; ft_vec3 direction; float length; float epsilon;
+} ft_ray;
+typedef struct ft_boundary { ft_vec3 center; float radius; } ft_boundary;/* Types.fs:19-24 (16 B) */
+typedef struct ft_sphere { ft_vec3 center; float radius; } ft_sphere;    /* SdfForm.fs:118-123 */
+typedef struct ft_capsule { ft_vec3 from; ft_vec3 to; float radius; } ft_capsule;        /* SdfForm.fs:137-143 */
+typedef struct ft_torus { ft_vec3 center; ft_vec3 normal; float major_radius; float minor_radius; } ft_torus; /* SdfForm.fs:172-179 */
+typedef struct ft_triangle { ft_vec3 v1; ft_vec3 v2; ft_vec3 v3; float radius; } ft_triangle;  /* SdfForm.fs:205-212 */
+typedef struct ft_box { ft_vec3 center; ft_vec3 half_extent; } ft_box;   /* EXTENSION: not in the reference */
+typedef struct ft_camera {                                               /* Camera.fs:16-22 (48 B) */
+    ft_vec3 position; ft_vec3 forward; ft_vec3 up_scaled; ft_vec3 right_scaled;
+} ft_camera;
+
+/* Image.render arguments (Image.fs:26) plus the column tiling used for multi-GPU.
+ * Local column c in [0, n_columns) maps to image column
+ *     x = x0 + (c / stripe_width) * stripe_width * stripe_ranks + stripe_rank * stripe_width + c % stripe_width
+ * (stripe_ranks = 1, stripe_rank = 0 gives the contiguous range [x0, x0 + n_columns)).
+ * Output is n_columns x height x 3 float32, column-major / y contiguous: exactly the
+ * FColor[X,Y] layout Array2D.Parallel.init produces (Array2D.fs:30-38). */
+typedef struct ft_render_params {
+    int32_t width, height;        /* ImageSize.X, ImageSize.Y (Image.fs:8-13) */
+    int32_t x0, n_columns;
+    int32_t stripe_width, stripe_ranks, stripe_rank;
+    int32_t spp;                  /* 1 = the reference (one corner sample). >1 is an EXTENSION. */
+    float epsilon, length;        /* Image.render's first two arguments */
+    int32_t ao_samples;           /* 0 = the reference. >0: EXTENSION ambient-occlusion rays */
+    float ao_radius;
+} ft_render_params;
+
+typedef struct ft_stats {         /* filled per call; all counts are exact */
+    uint64_t rays_primary, rays_shadow, rays_ext;
+    uint64_t hits_primary, hits_shadow;
+    uint64_t sdf_evals;           /* scene-SDF evaluations (march steps + normal probes) */
+    uint64_t flags;               /* bit0 NaN distance met, bit2 step cap hit (reference would not terminate) */
+    float kernel_ms;              /* HIP-event time of the render kernel(s) of this call */
+    float reserved;
+} ft_stats;
+
+/* ---- context ------------------------------------------------------------------------ */
+/* device >= 0: HIP device ordinal.  device = -1: host-only context (scene construction and
+ * ft_scene_export work; anything that needs the GPU fails with FT_ERR_NO_DEVICE). */
+int ft_abi_version(void);
+int ft_ctx_create(int device, ft_ctx** out);
+void ft_ctx_destroy(ft_ctx* ctx);
+const char* ft_last_error(void);
+/* use an existing HIP stream (e.g. torch's current stream) for all launches; NULL = own stream */
+int ft_ctx_set_stream(ft_ctx* ctx, void* hip_stream);
+
+/* ---- scene construction: one entry per reference constructor ---------------------------- */
+ft_handle ft_form_sphere(ft_ctx*, const ft_sphere*);                       /* SdfForm.Primitive.sphere  SdfForm.fs:125-135 */
+ft_handle ft_form_capsule(ft_ctx*, const ft_capsule*);                     /* SdfForm.Primitive.capsule SdfForm.fs:145-170 */
+ft_handle ft_form_torus(ft_ctx*, const ft_torus*);                         /* SdfForm.Primitive.torus   SdfForm.fs:181-203 */
+ft_handle ft_form_triangle(ft_ctx*, const ft_triangle*);                   /* SdfForm.Primitive.triangle SdfForm.fs:214-268 */
+ft_handle ft_form_box(ft_ctx*, const ft_box*);                             /* EXTENSION */
+ft_handle ft_form_union(ft_ctx*, const ft_handle* forms, int32_t n);       /* SdfForm.union        SdfForm.fs:14-40 */
+ft_handle ft_form_subtract(ft_ctx*, ft_handle a, ft_handle b);             /* SdfForm.subtract     SdfForm.fs:42-49 */
+ft_handle ft_form_intersect(ft_ctx*, const ft_handle* forms, int32_t n);   /* SdfForm.intersect    SdfForm.fs:51-67 */
+ft_handle ft_form_union_smooth(ft_ctx*, float strength, const ft_handle* forms, int32_t n); /* SdfForm.unionSmooth SdfForm.fs:69-91 */
+int ft_form_boundary(ft_ctx*, ft_handle form, ft_boundary* out);           /* SdfForm.Boundary */
+
+ft_handle ft_material_solid(ft_ctx*, const float rgb[3]);                  /* SdfMaterial.createSolid SdfMaterial.fs:4-7 */
+ft_handle ft_object_create(ft_ctx*, ft_handle material, ft_handle form);   /* SdfObject.create    SdfObject.fs:6-10 */
+ft_handle ft_object_union(ft_ctx*, const ft_handle* objects, int32_t n);   /* SdfObject.union     SdfObject.fs:12-48 */
+ft_handle ft_object_subtract(ft_ctx*, ft_handle object, ft_handle form);   /* SdfObject.subtract  SdfObject.fs:50-54 */
+ft_handle ft_object_intersect(ft_ctx*, ft_handle object, const ft_handle* forms, int32_t n); /* SdfObject.intersect SdfObject.fs:56-64 */
+ft_handle ft_object_form(ft_ctx*, ft_handle object);                       /* object.Form */
+
+ft_handle ft_light_directional(ft_ctx*, const float direction[3], const float rgb[3]);  /* SdfLight.directional SdfLight.fs:6-21 */
+ft_handle ft_light_point(ft_ctx*, const float position[3], const float rgb[3]);         /* SdfLight.point       SdfLight.fs:23-42 */
+
+/* SdfScene record (Types.fs:74-79): flattens the immutable tree and uploads it. */
+int ft_scene_create(ft_ctx*, ft_handle object, const float background_rgb[3],
+                    const ft_handle* lights, int32_t n_lights, ft_scene** out);
+void ft_scene_destroy(ft_scene*);
+
+/* Lens.create (Camera.fs:11-14) and Camera.lookAt (Camera.fs:33-42); host-side, once per frame. */
+float ft_lens_create(float field_of_view);
+int ft_camera_look_at(const float position[3], const float look_at[3], const float up[3],
+                      float near_plane_size, ft_camera* out);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* Image.render epsilon length imageSize camera (SdfScene.trace scene)  — Image.fs:26-35 +
+ * SdfScene.fs:7-28.  Synchronous.  `out` is host memory (pinned or pageable). */
+int ft_render(ft_ctx*, const ft_scene*, const ft_camera*, const ft_render_params*,
+              float* out, ft_stats* stats);
+/* Same, output left in device memory `d_out`, launched on the context's stream and NOT
+ * synchronised: for callers that keep the frame in HBM (multi-GPU gather, bench). */
+int ft_render_device(ft_ctx*, const ft_scene*, const ft_camera*, const ft_render_params*,
+                     void* d_out);
+/* counters / kernel time of the launches since the last call; synchronises the stream */
+int ft_collect_stats(ft_ctx*, ft_stats* stats);
+
+/* SdfScene.trace over an explicit ray buffer (the "ray buffer" form): out_rgb is n x 3 floats. */
+int ft_trace_rays(ft_ctx*, const ft_scene*, const ft_ray* rays, int64_t n, float* out_rgb, ft_stats* stats);
+
+/* scene.Object.Form.Distance at n points (+ index of the material the hit would pick, or
+ * NULL).  Test/diagnostic entry: lets parity tests compare single SDF evaluations. */
+int ft_eval_distance(ft_ctx*, const ft_scene*, const ft_vec3* points, int64_t n, float* out_distance, int32_t* out_material);
+
+/* Single-process multi-GPU form (what an F# host would call): the flattened scene is
+ * re-uploaded to each further device with ft_scene_clone, every device renders its column
+ * stripes (stripe_rank = index in ctxs[], stripe_ranks = n) on its own host thread, and the
+ * slabs are collected with ONE ncclGather to ctxs[0]'s device, de-interleaved
+ * there and copied to `out` (full width x height x 3 host image).  full_frame's stripe_* and
+ * x0/n_columns fields are ignored except stripe_width (0 = contiguous blocks of width/n). */
+int ft_scene_clone(const ft_scene* src, ft_ctx* dst_ctx, ft_scene** out);
+int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scenes, int32_t n,
+                    const ft_camera*, const ft_render_params* full_frame, float* out, ft_stats* stats);
+
+/* ---- introspection of the flattened scene (tests; not needed by a caller) ---------------- */
+typedef struct ft_scene_info {
+    int32_t n_instr, n_slots, n_consts, n_grids, n_children, n_cells, n_items, n_lights, n_materials;
+    int32_t fast_path;            /* which specialised evaluator the scene selected (0 = general) */
+} ft_scene_info;
+int ft_scene_info_get(const ft_scene*, ft_scene_info* out);
+/* grid g: info = aabbMin[3], cellSizeInv[3]; counts[3]; arrays sized from ft_scene_info /
+ * ft_scene_grid_shape: cell_start[ncells+1], centers[3*ncells], lower[nitems], child[nitems] */
+int ft_scene_grid_shape(const ft_scene*, int32_t g, float info[6], int32_t counts[3], int32_t* n_cells, int32_t* n_items);
+int ft_scene_grid_dump(const ft_scene*, int32_t g, uint32_t* cell_start, float* centers, float* lower, int32_t* child);
+
+/* math primitives of the device path, evaluated on the GPU: op 0 exp, 1 log, 2 sqrt, 3 a/b
+ * (y = second operand, may be NULL otherwise).  Used by tests/test_math_parity.py. */
+int ft_math_eval(ft_ctx*, int32_t op, const float* x, const float* y, int64_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAYTRACER_HIP_H */

@@ -1,0 +1,158 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle: bit-exact float32."""
+import numpy as np
+import pytest
+
+import fraytracer_amd as ft
+from fraytracer_amd import synthetic as syn
+from helpers import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+EPS, LEN = syn.EPSILON, syn.RAY_LENGTH
+
+
+def both(gpu, oracle, scene):
+    O = oracle.Oracle()
+    return gpu.scene(scene), O.scene(scene)
+
+
+def render_both(gpu, oracle, scene, W, H, **kw):
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    g, gst = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+    o, ocnt = os_.render(EPS, LEN, W, H, cam.as_array())
+    return g, gst, o, ocnt
+
+
+def check_counts(gst, ocnt):
+    assert gst["rays_primary"] == ocnt["rays_primary"]
+    assert gst["rays_shadow"] == ocnt["rays_shadow"]
+    assert gst["hits_primary"] == ocnt["hits_primary"]
+    assert gst["hits_shadow"] == ocnt["hits_shadow"]
+    assert gst["flags"] == ocnt["flags"] == 0
+
+
+def test_math_exp_log_sqrt_div(gpu, oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-110, 92, 2_000_000), rng.uniform(-2, 2, 1_000_000),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 88.72283, 88.72284, -103.97, -103.98, -104.5, 1e-40, -1e-40]]).astype(np.float32)
+    assert_bit_equal(gpu.math_eval(0, x), oracle.expf(x), "exp")
+    u = rng.integers(0, 0x7F800000, 3_000_000, dtype=np.uint32).view(np.float32)       # all positive finite floats incl. subnormals
+    u = np.concatenate([u, np.array([0.0, -0.0, np.inf, -1.0, np.nan, 1.0, 1e-45], np.float32)])
+    assert_bit_equal(gpu.math_eval(1, u), oracle.logf(u), "log")
+    assert_bit_equal(gpu.math_eval(2, u), oracle.sqrtf(u), "sqrt")
+    a = rng.integers(0, 0xFFFFFFFF, 2_000_000, dtype=np.uint32).view(np.float32)
+    b = rng.integers(0, 0xFFFFFFFF, 2_000_000, dtype=np.uint32).view(np.float32)
+    with np.errstate(all="ignore"):
+        assert_bit_equal(gpu.math_eval(3, a, b), a / b, "div")
+
+
+def test_c1_single_sphere(gpu, oracle):
+    scene, size = syn.config1()
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
+    assert_bit_equal(g, o, "C1 image")
+    check_counts(gst, ocnt)
+    # known answers: centre pixel hits after steps 9 -> 0; no lights -> Color * (bg * 1/pi)
+    want = np.float32(0.8) * (np.float32(0.1) * (np.float32(1) / np.float32(3.14159274)))
+    assert g[128, 128, 0] == want and g[0, 0, 0] == np.float32(0.1)
+
+
+@pytest.mark.parametrize("boxes", [False, True])
+def test_c2_union_of_32(gpu, oracle, boxes):
+    scene, _ = syn.config2(boxes=boxes)
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, 256, 256)
+    assert_bit_equal(g, o, "C2 image")
+    check_counts(gst, ocnt)
+    assert gst["rays_shadow"] > 0
+
+
+def test_c3_smooth_union_256(gpu, oracle):
+    scene, _ = syn.config3()
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, 128, 128)
+    assert_bit_equal(g, o, "C3 image")
+    check_counts(gst, ocnt)
+
+
+def test_console_like_scene(gpu, oracle):
+    scene, _ = syn.console_like(n=300)
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, 160, 160)
+    assert_bit_equal(g, o, "console-like image")
+    check_counts(gst, ocnt)
+
+
+@pytest.mark.parametrize("factory", [syn.random_sphere, syn.random_capsule, syn.random_torus, syn.random_triangle, syn.random_box])
+def test_console_structure_per_primitive(gpu, oracle, factory):
+    scene, _ = syn.console_like(seed=5, n=60, factory=factory)
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, 96, 96)
+    assert_bit_equal(g, o, factory.__name__)
+    check_counts(gst, ocnt)
+
+
+def test_mixed_nested_scene(gpu, oracle):
+    scene, size = syn.mixed_nested()
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
+    assert_bit_equal(g, o, "nested image")
+    check_counts(gst, ocnt)
+
+
+def test_non_square_and_ragged_sizes(gpu, oracle):
+    scene, _ = syn.config2(seed=11)
+    for W, H in [(37, 101), (130, 19), (1, 1), (8, 9)]:
+        g, gst, o, ocnt = render_both(gpu, oracle, scene, W, H)
+        assert_bit_equal(g, o, f"{W}x{H}")
+        check_counts(gst, ocnt)
+
+
+def test_eval_distance_and_material(gpu, oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-6, 6, (20000, 3)).astype(np.float32)
+    for scene in (syn.config2(seed=4)[0], syn.config3(n=40)[0], syn.console_like(n=120)[0], syn.mixed_nested()[0]):
+        ds, os_ = both(gpu, oracle, scene)
+        d, m = ds.eval_distance(pts)
+        O = oracle.Oracle()
+        want = O.form_distance(O.object_form(os_.object), pts)
+        assert_bit_equal(d, want, "Form.Distance")
+
+
+def test_trace_rays_matches_oracle_and_render(gpu, oracle):
+    scene, _ = syn.console_like(n=150)
+    ds, os_ = both(gpu, oracle, scene)
+    cam = syn.default_camera()
+    W = H = 64
+    rays = np.stack([oracle.pixel_ray(cam.as_array(), W, H, x, y, EPS, LEN) for x in range(W) for y in range(H)])
+    g, gst = ds.trace_rays(rays)
+    o, ocnt = os_.trace_rays(rays)
+    assert_bit_equal(g, o, "trace_rays")
+    img, _ = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+    assert_bit_equal(g.reshape(W, H, 3), img, "ray buffer vs Image.render")
+    # arbitrary rays: random origins/directions, per-ray epsilon and length, zero-length ray -> background
+    rng = np.random.default_rng(9)
+    n = 5000
+    r = np.zeros((n, 8), np.float32)
+    r[:, 0:3] = rng.uniform(-8, 8, (n, 3))
+    d = rng.normal(size=(n, 3)); r[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    r[:, 6] = rng.uniform(0, 40, n); r[:, 7] = rng.choice([0.01, 0.003, 0.05], n)
+    r[0, 6] = 0.0; r[1, 6] = -1.0
+    g, _ = ds.trace_rays(r)
+    o, _ = os_.trace_rays(r)
+    assert_bit_equal(g, o, "arbitrary rays")
+    assert tuple(g[0]) == tuple(np.float32(syn.BACKGROUND))
+
+
+def test_column_tiles_concatenate_to_full_frame(gpu):
+    scene, _ = syn.config2(seed=6)
+    cam = syn.default_camera()
+    ds = gpu.scene(scene)
+    W, H = 192, 80
+    full, _ = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+    # contiguous tiles
+    parts = [ds.render(EPS, LEN, ft.ImageSize(W, H), cam, x0=x0, n_columns=48)[0] for x0 in range(0, W, 48)]
+    assert_bit_equal(np.concatenate(parts, 0), full, "contiguous tiles")
+    # interleaved stripes of 16 columns over 4 ranks
+    S, R = 16, 4
+    out = np.empty_like(full)
+    for r in range(R):
+        slab, _ = ds.render(EPS, LEN, ft.ImageSize(W, H), cam, stripe_width=S, stripe_ranks=R, stripe_rank=r)
+        for j in range(slab.shape[0] // S):
+            out[(j * R + r) * S:(j * R + r + 1) * S] = slab[j * S:(j + 1) * S]
+    assert_bit_equal(out, full, "striped tiles")
