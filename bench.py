@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (primary + shadow rays) of the FrayTracer hot path on MI355X.
+
+A "step" renders one synthetic frame of BASELINE.json configs[2]: the 256-sphere smooth-union scene
+at 4096x4096 (SURVEY.md §8d "C3"; 1 sample per pixel = the reference's own sampling — spp > 1 is an
+extension and is not what `value` is measured on).  With --gpus N the SAME frame is split into
+interleaved column stripes over N ranks (one process per GPU, launched by torch.distributed.run),
+each rank renders its stripes with the HIP kernel into HBM, and ONE RCCL gather per frame brings
+the slabs to rank 0, which de-interleaves them: total work is fixed, so scaling is "strong".
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the f32 VALU peak
+(256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s; no FMA contraction is
+allowed by the parity requirement); `cpu_baseline` times the CPU oracle (a C++ restatement of the
+F# CPU path — NOT the F# program) on a bounded sample of the same frame on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VALU_PEAK_TLANEOPS = 78.6          # SURVEY.md §8d / MI355X_MICROARCH.md chip table
+STRIPE = 16                        # columns per stripe when N > 1
+
+
+def algorithmic_flops(stats, n_children, flops_per_child=13, flops_per_eval=3):
+    """per SDF eval of the C3 scene 256 x (sphere 10 + smooth-union 3) + 3 = 3331;
+    + 8 per march step, 20 per normal, 25 per shaded light.  Counts are the kernel's own exact
+    counters (deterministic for a scene; equal to the oracle's for rays/hits)."""
+    evals = stats["sdf_evals"]
+    normals = stats["hits_primary"]
+    steps = evals - 4 * normals
+    return evals * (n_children * flops_per_child + flops_per_eval) + 8 * steps + 20 * normals + 25 * stats["rays_shadow"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096, help="frame is size x size (default: the metric's 4096)")
+    ap.add_argument("--spheres", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-columns", type=int, default=32, help="columns of the frame the CPU oracle is timed on")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fraytracer_amd as ft
+    from fraytracer_amd import synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs through torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: fraytracer_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W = H = args.size
+    if W % (STRIPE * world) != 0:
+        raise SystemExit(f"size must be a multiple of {STRIPE * world}")
+    scene, _ = syn.config3(n=args.spheres, size=W)
+    cam = syn.default_camera()
+    dev = ft.Device(local_rank)
+    stream = torch.cuda.current_stream()
+    dev.set_stream(stream.cuda_stream)            # kernel, its HIP events and the collective share one stream
+    ds = dev.scene(scene)
+    size = ft.ImageSize(W, H)
+    cols = W // world
+    slab = torch.empty((cols, H, 3), dtype=torch.float32, device="cuda")
+    gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
+    frame = torch.empty((W, H, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+    tiling = dict(stripe_width=STRIPE, stripe_ranks=world, stripe_rank=rank, n_columns=cols) if world > 1 else {}
+
+    def step():
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
+        if world > 1:
+            dist.gather(slab, gathered, dst=0)    # the ONE collective of the path (RCCL over xGMI)
+            if rank == 0:                         # stripe j of rank r -> columns [(j*world + r)*STRIPE, +STRIPE)
+                g = torch.stack(gathered).view(world, cols // STRIPE, STRIPE, H, 3)
+                frame.view(cols // STRIPE, world, STRIPE, H, 3).copy_(g.permute(1, 0, 2, 3, 4))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ds.collect_stats()                            # drop warm-up counters / events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st = ds.collect_stats()                       # exact counters + HIP-event kernel time of the K timed launches
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"]],
+                       dtype=torch.int64, device="cuda")
+    kms = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    rays_primary, rays_shadow, evals, hits, flags = (int(v) for v in cnt.tolist())
+
+    if rank == 0:
+        rays = rays_primary + rays_shadow
+        mrays = rays / dt / 1e6
+        # roofline of the dominant (only) kernel, from this rank's launches: algorithmic lane-ops per
+        # launch / mean HIP-event duration of a launch
+        flops_launch = algorithmic_flops(st, args.spheres) / args.steps
+        launch_s = st["kernel_ms"] / 1e3 / args.steps
+        achieved = flops_launch / launch_s / 1e12
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 4096x4096; max per-pixel |delta| vs F# ref",
+            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: unionSmooth(0.25) of {args.spheres} spheres, {W}x{H}, 1 spp, 1 directional light "
+                                   "(shadow rays = secondary rays), eps 0.01, ray length 30",
+                       "rays_per_frame": rays // args.steps, "primary": rays_primary // args.steps,
+                       "shadow": rays_shadow // args.steps, "sdf_evals_per_frame": evals // args.steps,
+                       "parallelism": f"column stripes of {STRIPE} over {world} GPU(s) + 1 RCCL gather" if world > 1 else "1 GPU",
+                       "nan_or_cap_flags": flags},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": None,
+                         "kernel": "ft_trace_kernel", "kernel_ms": round(launch_s * 1e3, 3),
+                         "algorithmic_flops_per_launch": int(flops_launch),
+                         "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity). HBM traffic is "
+                                 "12 B/pixel output only; see profiles/ for the PMC capture"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, cam, W, H, args.cpu_columns)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, cam, W, H, ncols):
+    """Time the CPU oracle on every (W/ncols)-th column of the same frame, all host threads."""
+    from oracle import binding as ob
+    threads = os.cpu_count() or 1
+    osc = ob.Oracle().scene(scene)
+    xstep = max(1, W // ncols)
+    t0 = time.perf_counter()
+    _, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
+    dt = time.perf_counter() - t0
+    rays = cnt["rays_primary"] + cnt["rays_shadow"]
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"every {xstep}th column of the same {W}x{H} frame ({(W + xstep - 1) // xstep} columns, {rays} rays, {dt:.1f} s); "
+                      "oracle = C++ restatement of the F# CPU path, std::function closures, x-column work queue",
+            "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

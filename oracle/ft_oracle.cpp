@@ -871,26 +871,28 @@ int orc_trace_rays(int scene, const float* rays, int64_t n, float* out, orc_coun
 // Image.render (Image.fs:26-35) over columns [x0, x1) of a W x H image; out is
 // (x1-x0) x H x 3 floats, x-major / y contiguous like FColor[X,Y] (Array2D.fs:30-38).
 // Threading mirrors Array2D.fs:32: workers pull whole x-columns.
-int orc_render(int scene, const float cam[12], int W, int H, int x0, int x1,
+// `xstep` > 1 renders only columns x0, x0+xstep, ... (< x1): the bounded sample bench.py times.
+int orc_render_strided(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
                float epsilon, float length, float* out, int nthreads, orc_counters* cnt) {
     if (scene < 0 || (size_t)scene >= g_scenes.size()) return fail("bad scene handle");
-    if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1) return fail("bad image range");
+    if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1 || xstep < 1) return fail("bad image range");
     const SdfScene& sc = g_scenes[scene];
     const Camera camera = ldcam(cam);
     const float maxSize = (float)std::max(W, H);                             // Image.fs:18
     if (nthreads < 1) nthreads = 1;
-    std::atomic<int> next(x0);
+    std::atomic<int> next(0);
     std::vector<Counters> per(nthreads);
     auto worker = [&](int tid) {
         tl_cnt = Counters{}; tl_flags = 0;
         for (;;) {
-            int x = next.fetch_add(1);
+            const int col = next.fetch_add(1);
+            const int x = x0 + col * xstep;
             if (x >= x1) break;
             for (int y = 0; y < H; ++y) {                                    // Array2D.fs:33
                 V2 pos{(float)x / maxSize, (float)y / maxSize};              // Image.fs:20-23,30
                 Ray ray = Camera_uniformPixelToRay(epsilon, length, camera, pos);  // Image.fs:32
                 FColor c = Scene_trace(sc, ray);                             // Image.fs:34
-                float* o = out + ((size_t)(x - x0) * H + y) * 3;
+                float* o = out + ((size_t)col * H + y) * 3;
                 o[0] = c.c.X; o[1] = c.c.Y; o[2] = c.c.Z;
             }
         }
@@ -905,6 +907,11 @@ int orc_render(int scene, const float cam[12], int W, int H, int x0, int x1,
     }
     if (cnt) { Counters tot{}; for (auto& c : per) addCounters(tot, c); memcpy(cnt, &tot, sizeof(Counters)); }
     return 0;
+}
+
+int orc_render(int scene, const float cam[12], int W, int H, int x0, int x1,
+               float epsilon, float length, float* out, int nthreads, orc_counters* cnt) {
+    return orc_render_strided(scene, cam, W, H, x0, x1, 1, epsilon, length, out, nthreads, cnt);
 }
 
 // primary ray for one pixel (Image.fs:30-32) — lets tests feed identical rays to both sides
