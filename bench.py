@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="frame is size x size (default: the metric's 4096)")
     ap.add_argument("--spheres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-columns", type=int, default=32, help="columns of the frame the CPU oracle is timed on")
+    ap.add_argument("--cpu-columns", type=int, default=0,
+                    help="columns of the frame the CPU oracle is timed on (default: 4 per host thread, at least 32)")
     args = ap.parse_args()
 
     import numpy as np
@@ -161,6 +162,8 @@ def cpu_baseline(scene, cam, W, H, ncols):
     from oracle import binding as ob
     threads = os.cpu_count() or 1
     osc = ob.Oracle().scene(scene)
+    if ncols <= 0:
+        ncols = max(32, 4 * threads)          # the oracle's work queue hands out whole columns (Array2D.fs:32)
     xstep = max(1, W // ncols)
     t0 = time.perf_counter()
     _, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)

@@ -119,6 +119,7 @@ SYMBOLS = {
     "ft_scene_grid_shape": (C.c_int, [_P, C.c_int32, _F3, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ft_scene_grid_dump": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "ft_math_eval": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "ft_selftest_fastmath": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
 }
 
 

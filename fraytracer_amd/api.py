@@ -291,6 +291,11 @@ class Device:
                 scene._realised[id(self)] = got
             return got
 
+    def selftest_fastmath(self):
+        m = (C.c_uint64 * 2)()
+        check(lib.ft_selftest_fastmath(self._ctx, m))
+        return {"sqrt": int(m[0]), "exp": int(m[1])}
+
     def math_eval(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)

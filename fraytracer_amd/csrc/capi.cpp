@@ -93,6 +93,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d = FtSceneDev{};
     d.nInstr = (uint32_t)f.instr.size(); d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
+    d.nStage = f.nStage;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));
@@ -110,7 +111,8 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     return FT_OK;
 }
 
-size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8; }
+// per-lane value slots (distance + material index) followed by the staged constant-pool prefix
+size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4; }
 
 int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
     if (!c->eventPool.empty()) { a = c->eventPool.back().first; b = c->eventPool.back().second; c->eventPool.pop_back(); return FT_OK; }
@@ -401,7 +403,7 @@ int ft_eval_distance(ft_ctx* c, const ft_scene* s, const ft_vec3* pts, int64_t n
 
 int ft_math_eval(ft_ctx* c, int32_t op, const float* x, const float* y, int64_t n, float* out) {
     int rc = requireDevice(c); if (rc) return rc;
-    if (!x || !out || n < 0 || op < 0 || op > 3 || (op == 3 && !y)) return setErr(FT_ERR_INVALID, "bad argument");
+    if (!x || !out || n < 0 || op < 0 || op > 5 || (op == 3 && !y)) return setErr(FT_ERR_INVALID, "bad argument");
     if (n == 0) return FT_OK;
     const size_t b = align256((size_t)n * 4);
     if ((rc = ensureScratch(c, 3 * b))) return rc;
@@ -412,6 +414,23 @@ int ft_math_eval(ft_ctx* c, int32_t op, const float* x, const float* y, int64_t 
                            reinterpret_cast<float*>(base + 2 * b), c->stream));
     HIP_TRY(hipMemcpyAsync(out, base + 2 * b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return FT_OK;
+}
+
+int ft_selftest_fastmath(ft_ctx* c, uint64_t mismatches[2]) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!mismatches) return setErr(FT_ERR_INVALID, "null output");
+    if ((rc = ensureScratch(c, 256))) return rc;
+    unsigned long long* d = static_cast<unsigned long long*>(c->scratch);
+    HIP_TRY(hipMemsetAsync(d, 0, 16, c->stream));
+    // sqrt: every float in [2^-96, 2^100]; exp: every float in [-87, -0] and [+0, 88]
+    HIP_TRY(ft_launch_selftest(0, 0x0F800000u, 0x71800000u, d, c->stream));
+    HIP_TRY(ft_launch_selftest(1, 0x80000000u, 0xC2AE0000u, d + 1, c->stream));
+    HIP_TRY(ft_launch_selftest(1, 0x00000000u, 0x42B00000u, d + 1, c->stream));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    mismatches[0] = h[0]; mismatches[1] = h[1];
     return FT_OK;
 }
 

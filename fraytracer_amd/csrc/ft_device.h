@@ -82,7 +82,7 @@ struct FtSceneDev {             // passed by value as kernel argument
     const float* materials;     // 3 floats per material
     uint32_t nInstr, nSlots, nLights, fastPath;
     float bg[3];
-    float pad;
+    uint32_t nStage;            // leading floats of consts[] that every workgroup stages into LDS
 };
 
 struct FtStatsDev {
@@ -91,3 +91,6 @@ struct FtStatsDev {
 
 #define FT_STEP_CAP (1u << 20)  // the reference has no cap (SdfForm.fs:93-104); see DESIGN.md "NaN / step cap"
 #define FT_MAX_SLOTS 48
+#define FT_FLAG_INIT 1u         // FtInstr.flags: accumulator starts at 0 (first child of a smooth union)
+#define FT_FLAG_FAST 2u         // FtInstr.flags: sphere run whose parameters admit the guarded fast path (see scene.cpp)
+#define FT_MAX_STAGE_FLOATS 12288   // <= 48 KB of the constant pool is mirrored in LDS

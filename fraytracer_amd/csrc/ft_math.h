@@ -83,8 +83,10 @@ FT_HD int ft_sign_i(float x) { return x < 0.0f ? -1 : (x > 0.0f ? 1 : 0); }
 FT_HD float ft_exp(float x) {
     if (x != x) return x;
     x = x < -104.0f ? -104.0f : (x > 89.0f ? 89.0f : x);
-    const float t = x * 0x1.715476p+0f;               // log2(e)
-    const float n = rintf(t);                          // round-half-even (v_rndne_f32)
+    // n = round-half-even(x * log2e) with ONE rounding: fma onto 1.5*2^23 (ulp 1); the integer n
+    // also sits in the low mantissa bits of tm, which the device fast path shifts into the exponent
+    const float tm = fmaf(x, 0x1.715476p+0f, 12582912.0f);
+    const float n = tm - 12582912.0f;
     float r = fmaf(n, -0x1.62e4p-1f, x);               // - n*ln2_hi (exact product)
     r = fmaf(n, -0x1.7f7d1cp-20f, r);                  // - n*ln2_lo
     float q = 0x1.6d110ap-10f;
@@ -95,7 +97,7 @@ FT_HD float ft_exp(float x) {
     const float r2 = r * r;
     const float s = fmaf(q, r2, r);
     const float p = s + 1.0f;
-    return ldexpf(p, (int)n);
+    return ldexpf(p, (int)(ft_bits(tm) - 0x4B400000u));
 }
 
 FT_HD double ft_log_f64(double x) {                    // fdlibm e_log.c structure; x finite, > 0, normal

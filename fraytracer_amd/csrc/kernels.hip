@@ -23,13 +23,32 @@
 // primitives (SdfForm.fs:125-268).  `c` points at the primitive's constant-pool record; when the
 // index is wave-uniform the compiler turns these into scalar loads.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f3 ld3(const float* __restrict__ c) { return mk3(c[0], c[1], c[2]); }
+// Scene data is immutable for the whole launch.  Reading it through the constant address space lets
+// the compiler use scalar loads (s_load_dwordx4/x8) whenever the address is wave-uniform — one SMEM
+// fetch per primitive per wave instead of a 64-lane vector load — and plain global loads otherwise.
+#define FT_CONST __attribute__((address_space(4)))
+typedef const float FT_CONST* cfp;
+template <class T> __device__ __forceinline__ const T FT_CONST* as_const(const T* p) {
+    return (const T FT_CONST*)(p);
+}
 
-__device__ __forceinline__ float prim_sphere(const float* __restrict__ c, f3 p) {
+__device__ __forceinline__ f3 ld3(cfp c) { return mk3(c[0], c[1], c[2]); }
+// structs cannot be copy-constructed across address spaces: field-wise loaders
+__device__ __forceinline__ FtInstr ld_instr(const FtInstr FT_CONST* q) {
+    FtInstr r; r.op = q->op; r.dst = q->dst; r.src = q->src; r.type = q->type; r.count = q->count; r.data = q->data;
+    r.aux = q->aux; r.flags = q->flags; r.f0 = q->f0; r.f1 = q->f1; r.pad0 = 0; r.pad1 = 0; return r;
+}
+__device__ __forceinline__ FtItem ld_item(const FtItem FT_CONST* q) { FtItem r; r.lowerBound = q->lowerBound; r.child = q->child; return r; }
+__device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
+    FtLight r; r.type = q->type; r.v[0] = q->v[0]; r.v[1] = q->v[1]; r.v[2] = q->v[2];
+    r.color[0] = q->color[0]; r.color[1] = q->color[1]; r.color[2] = q->color[2]; r.pad = 0.0f; return r;
+}
+
+__device__ __forceinline__ float prim_sphere(cfp c, f3 p) {
     return ft_distance(ld3(c), p) - c[3];                              // SdfForm.fs:129
 }
 
-__device__ __forceinline__ float prim_capsule(const float* __restrict__ c, f3 p) {
+__device__ __forceinline__ float prim_capsule(cfp c, f3 p) {
     const f3 diff = p - ld3(c);                                        // :153
     const f3 dir = ld3(c + 4);
     const float t = ft_dot(diff, ld3(c + 8));                          // :154
@@ -39,7 +58,7 @@ __device__ __forceinline__ float prim_capsule(const float* __restrict__ c, f3 p)
     return ft_distance(diff, w) - c[3];                                // :164
 }
 
-__device__ __forceinline__ float prim_torus(const float* __restrict__ c, f3 p) {
+__device__ __forceinline__ float prim_torus(cfp c, f3 p) {
     const f3 n = ld3(c + 4);
     const float distanceToPlane = ft_dot(p, n) + c[8];                 // :190
     const float distanceToCenter = ft_distance(ld3(c), p - (distanceToPlane * n));   // :191
@@ -47,7 +66,7 @@ __device__ __forceinline__ float prim_torus(const float* __restrict__ c, f3 p) {
     return sqrtf(distanceToPlane * distanceToPlane + distanceToCircle * distanceToCircle) - c[7];   // :194
 }
 
-__device__ __forceinline__ float prim_triangle(const float* __restrict__ c, f3 p) {
+__device__ __forceinline__ float prim_triangle(cfp c, f3 p) {
     const f3 p1 = p - ld3(c), p2 = p - ld3(c + 4), p3 = p - ld3(c + 8);   // :228-230
     float distance;
     const int s = ft_sign_i(ft_dot(ld3(c + 40), p1)) + ft_sign_i(ft_dot(ld3(c + 44), p2)) + ft_sign_i(ft_dot(ld3(c + 48), p3));
@@ -63,14 +82,14 @@ __device__ __forceinline__ float prim_triangle(const float* __restrict__ c, f3 p
     return distance - c[3];                                            // :250
 }
 
-__device__ __forceinline__ float prim_box(const float* __restrict__ c, f3 p) {   // EXTENSION
+__device__ __forceinline__ float prim_box(cfp c, f3 p) {   // EXTENSION
     const f3 d = p - ld3(c);
     const f3 q = mk3(fabsf(d.x) - c[4], fabsf(d.y) - c[5], fabsf(d.z) - c[6]);
     const f3 qp = mk3(ft_max(q.x, 0.0f), ft_max(q.y, 0.0f), ft_max(q.z, 0.0f));
     return ft_length(qp) + ft_min(ft_max(q.x, ft_max(q.y, q.z)), 0.0f);
 }
 
-__device__ __forceinline__ float prim_eval(uint32_t type, const float* __restrict__ c, f3 p) {
+__device__ __forceinline__ float prim_eval(uint32_t type, cfp c, f3 p) {
     switch (type) {
         case FT_PR_SPHERE: return prim_sphere(c, p);
         case FT_PR_CAPSULE: return prim_capsule(c, p);
@@ -91,11 +110,91 @@ __device__ __forceinline__ uint32_t prim_stride(uint32_t type) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Guarded fast forms of sqrt and exp for the uniform smooth-union loop.  Both give bit-identical
+// results to sqrtf / ft_exp on their stated ranges (proved by exhaustion over every float in the
+// range: ft_selftest_fastmath, tests/test_gpu_parity.py); callers fall back outside.
+//   ft_sqrt_fast: q in [2^-96, 2^100].  v_rsq_f32 seed + one coupled Newton step on (s, h) + one
+//                 residual correction: 1 quarter-rate + 7 full-rate ops, no compares/selects
+//                 (hipcc's IEEE sqrtf is ~17 instructions with denormal scaling and fix-ups).
+//   ft_exp_fast:  t in [-87, 88]: the result is normal, so 2^n is applied by adding n to the exponent
+//                 field (v_lshl_add_u32) instead of cvt + v_ldexp_f32 (both half rate), and no clamps.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ft_sqrt_fast(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r;
+    float h = 0.5f * r;
+    const float e = fmaf(-h, s, 0.5f);
+    h = fmaf(h, e, h);
+    s = fmaf(s, e, s);
+    const float d = fmaf(-s, s, x);
+    return fmaf(d, h, s);
+}
+
+__device__ __forceinline__ float ft_exp_fast(float x) {
+    const float tm = fmaf(x, 0x1.715476p+0f, 12582912.0f);
+    const float n = tm - 12582912.0f;
+    float r = fmaf(n, -0x1.62e4p-1f, x);
+    r = fmaf(n, -0x1.7f7d1cp-20f, r);
+    float q = 0x1.6d110ap-10f;
+    q = fmaf(q, r, 0x1.120b6ep-7f);
+    q = fmaf(q, r, 0x1.55551ap-5f);
+    q = fmaf(q, r, 0x1.5554dcp-3f);
+    q = fmaf(q, r, 0x1.0p-1f);
+    const float r2 = r * r;
+    const float sres = fmaf(q, r2, r);
+    const float pz = sres + 1.0f;
+    return __uint_as_float((__float_as_uint(tm) << 23) + __float_as_uint(pz));
+}
+
+#define FT_FAST_T_MIN (-87.0f)
+#define FT_FAST_Q_MIN_BITS 0x0F800000u     // 2^-96
+
+// sum += exp(si * (|c_i - p| - r_i)) for `count` spheres whose (c, r) records sit in LDS at ldsC
+// (SdfForm.fs:77-80 with sphere children, :129).  Four children per step: their parameter reads are
+// LDS broadcasts (ds_read_b128, no SGPR operands: those halve the VALU rate on gfx950) and their
+// four dependency chains interleave.  The additions into `sum` stay in child order.
+__device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si, f3 p, float sum) {
+    uint32_t i = 0;
+    for (; i + 4 <= count; i += 4) {
+        float4 prm[4];
+        float q[4], t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prm[j] = *reinterpret_cast<const float4*>(ldsC + 4 * (i + j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
+            q[j] = (dx * dx + dy * dy) + dz * dz;
+        }
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = si * (ft_sqrt_fast(q[j]) - prm[j].w);
+            bad |= !(t[j] >= FT_FAST_T_MIN);                         // also catches NaN / inf / huge q
+        }
+        const uint32_t qmin = min(min(__float_as_uint(q[0]), __float_as_uint(q[1])), min(__float_as_uint(q[2]), __float_as_uint(q[3])));
+        bad |= qmin < FT_FAST_Q_MIN_BITS;                            // q >= +0, so integer order = float order
+        if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum = sum + ft_exp(si * (sqrtf(q[j]) - prm[j].w));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum = sum + ft_exp_fast(t[j]);
+        }
+    }
+    for (; i < count; ++i) {
+        const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
+        const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
+        sum = sum + ft_exp(si * (sqrtf((dx * dx + dy * dy) + dz * dz) - prm.w));
+    }
+    return sum;
+}
+
+// ------------------------------------------------------------------------------------------------
 // union through the uniform grid: SdfBoundary.fs:276-282 lookup, SdfForm.fs:22-34 fold, with the
 // argmin of SdfObject.fs:27-46 tracked in the same sweep (same grid, same tests, strict '<').
 // Per-lane candidate list; lanes of a wave are neighbouring pixels and mostly share the cell.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid& g, const f3 p,
+__device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            const float* __restrict__ sd, const uint32_t* __restrict__ sl,
                                            float& outD, uint32_t& outLeaf) {
     const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
@@ -103,26 +202,29 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid& g,
     const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
     const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
     const uint32_t cell = g.cellBase + (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz);
-    const float* ctr = S.cellCenters + 3u * cell;
+    cfp ctr = as_const(S.cellCenters) + 3u * cell;
     const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
-    uint32_t i = S.cellStart[cell];
-    const uint32_t end = S.cellStart[cell + 1];
-    const FtChild* kids = S.children + g.childBase;
+    const uint32_t FT_CONST* cellStart = as_const(S.cellStart);
+    const FtItem FT_CONST* items = as_const(S.items);
+    cfp consts = as_const(S.consts);
+    uint32_t i = cellStart[cell];
+    const uint32_t end = cellStart[cell + 1];
+    const FtChild FT_CONST* kids = as_const(S.children) + g.childBase;
 
     float mn; uint32_t leaf;
     {                                                                  // Items.[0]  (SdfForm.fs:26)
-        const FtChild& k = kids[S.items[i].child];
+        const FtChild FT_CONST& k = kids[items[i].child];
         if (k.type == FT_PR_SLOT) { mn = sd[k.data * FT_BLOCK]; leaf = sl[k.data * FT_BLOCK]; }
-        else { mn = prim_eval(k.type, S.consts + k.data, p); leaf = k.mat; }
+        else { mn = prim_eval(k.type, consts + k.data, p); leaf = k.mat; }
     }
     for (++i; i < end; ++i) {                                          // SdfForm.fs:27
-        const FtItem it = S.items[i];
+        const FtItem it = ld_item(items + i);
         if (mn > it.lowerBound - distanceToCenter) {                   // :30
-            const FtChild& k = kids[it.child];
+            const FtChild FT_CONST& k = kids[it.child];
             if (mn > ft_distance(mk3(k.bc[0], k.bc[1], k.bc[2]), p) - k.br) {   // :31 getMinDistance
                 float d; uint32_t l;
                 if (k.type == FT_PR_SLOT) { d = sd[k.data * FT_BLOCK]; l = sl[k.data * FT_BLOCK]; }
-                else { d = prim_eval(k.type, S.consts + k.data, p); l = k.mat; }
+                else { d = prim_eval(k.type, consts + k.data, p); l = k.mat; }
                 if (d < mn) leaf = l;                                  // SdfObject.fs:41-43
                 mn = ft_min(mn, d);                                    // SdfForm.fs:33
             }
@@ -137,23 +239,28 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid& g,
 // the reference's material closure would pick at p.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
-                                        float& outD, uint32_t& outLeaf) {
+                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
+    cfp consts = as_const(S.consts);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
-        const FtInstr in = S.instr[pc];
+        const FtInstr in = ld_instr(as_const(S.instr) + pc);
         float* dst = sd + in.dst * FT_BLOCK;
         switch (in.op) {
         case FT_OP_PRIM:
-            *dst = prim_eval(in.type, S.consts + in.data, p);
+            *dst = prim_eval(in.type, consts + in.data, p);
             break;
         case FT_OP_SETLEAF:
             sl[in.dst * FT_BLOCK] = in.aux;
             break;
         case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
             float sum = (in.flags & 1u) ? 0.0f : *dst;
-            const float* c = S.consts + in.data;
-            const uint32_t stride = prim_stride(in.type);
-            for (uint32_t i = 0; i < in.count; ++i)
-                sum = sum + ft_exp(in.f0 * prim_eval(in.type, c + i * stride, p));
+            if ((in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
+                sum = smooth_run_spheres_fast(ldsC + in.data, in.count, in.f0, p, sum);
+            } else {
+                cfp c = consts + in.data;
+                const uint32_t stride = prim_stride(in.type);
+                for (uint32_t i = 0; i < in.count; ++i)
+                    sum = sum + ft_exp(in.f0 * prim_eval(in.type, c + i * stride, p));
+            }
             *dst = sum;
             break;
         }
@@ -170,8 +277,8 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
             break;
         case FT_OP_ISECT_RUN: {                                        // SdfForm.fs:60-63
             float mx = *dst;
-            const float* c = S.consts + in.data;
-            const float* bd = S.consts + in.aux;
+            cfp c = consts + in.data;
+            cfp bd = consts + in.aux;
             const uint32_t stride = prim_stride(in.type);
             for (uint32_t i = 0; i < in.count; ++i) {
                 const float v = prim_eval(in.type, c + i * stride, p);
@@ -181,14 +288,14 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
             break;
         }
         case FT_OP_ISECT_APPLY: {
-            const float* bd = S.consts + in.aux;
+            cfp bd = consts + in.aux;
             const float mx = *dst;
             if (mx < ft_distance(ld3(bd), p) + bd[3]) *dst = ft_max(mx, sd[in.src * FT_BLOCK]);
             break;
         }
         case FT_OP_UNION: {
             float d; uint32_t l;
-            eval_union(S, S.grids[in.aux], p, sd, sl, d, l);
+            eval_union(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
             *dst = d; sl[in.dst * FT_BLOCK] = l;
             break;
         }
@@ -243,13 +350,13 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
         }
         if (s.phase == PH_LIGHTS) {
             if (s.lidx >= a.S.nLights) {                               // SdfScene.fs:28
-                const float* m = a.S.materials + 3u * s.leaf;
+                cfp m = as_const(a.S.materials) + 3u * s.leaf;
                 const f3 color = mk3(m[0], m[1], m[2]);
                 write_rgb(a.out, s.outIdx, color * (s.lacc * piInv));
                 s.phase = PH_IDLE;
                 return;
             }
-            const FtLight L = a.S.lights[s.lidx];
+            const FtLight L = ld_light(as_const(a.S.lights) + s.lidx);
             const f3 lv = mk3(L.v[0], L.v[1], L.v[2]);
             const f3 lc = mk3(L.color[0], L.color[1], L.color[2]);
             f3 ldir;
@@ -316,6 +423,9 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtR
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     float* sd = ft_lds + tid;
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + a.S.nSlots * FT_BLOCK) + tid;
+    float* ldsC = ft_lds + 2u * a.S.nSlots * FT_BLOCK;                // staged constant pool ("SDF op stack" in LDS)
+    for (uint32_t i = tid; i < a.S.nStage; i += FT_BLOCK) ldsC[i] = a.S.consts[i];
+    __syncthreads();
 
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
     bool exhausted = false;
@@ -361,7 +471,7 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtR
                 if (s.phase == PH_NZ) q.z = base.z + h;
             }
             float d; uint32_t leaf;
-            ft_eval(a.S, q, sd, sl, d, leaf);
+            ft_eval(a.S, q, sd, sl, ldsC, d, leaf);
             s.cEvals += 1;
 
             switch (s.phase) {
@@ -420,9 +530,12 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(con
     const uint32_t tid = threadIdx.x;
     float* sd = ft_lds + tid;
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + S.nSlots * FT_BLOCK) + tid;
+    float* ldsC = ft_lds + 2u * S.nSlots * FT_BLOCK;
+    for (uint32_t i = tid; i < S.nStage; i += FT_BLOCK) ldsC[i] = S.consts[i];
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * FT_BLOCK + tid; i < n; i += (long long)gridDim.x * FT_BLOCK) {
         float d; uint32_t leaf;
-        ft_eval(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, d, leaf);
+        ft_eval(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, ldsC, d, leaf);
         outD[i] = d;
         if (outM) outM[i] = (int)leaf;
     }
@@ -437,10 +550,25 @@ extern "C" __global__ void ft_math_kernel(int op, const float* __restrict__ x, c
             case 0: r = ft_exp(v); break;
             case 1: r = ft_log(v); break;
             case 2: r = sqrtf(v); break;
+            case 4: r = ft_sqrt_fast(v); break;
+            case 5: r = ft_exp_fast(v); break;
             default: r = v / y[i]; break;
         }
         out[i] = r;
     }
+}
+
+// exhaustive proof of the fast forms: every float bit pattern in [lo, hi] (same sign), fast vs exact
+extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long u = (unsigned long long)lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= hi;
+         u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)u);
+        const float a = op == 0 ? ft_sqrt_fast(x) : ft_exp_fast(x);
+        const float b = op == 0 ? sqrtf(x) : ft_exp(x);
+        bad += __float_as_uint(a) != __float_as_uint(b);
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,6 +585,10 @@ extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pt
 }
 extern "C" hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(ft_math_kernel, dim3(1024), dim3(256), 0, st, op, x, y, n, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st) {
+    hipLaunchKernelGGL(ft_selftest_kernel, dim3(4096), dim3(256), 0, st, op, lo, hi, d_mismatches);
     return hipGetLastError();
 }
 extern "C" hipError_t ft_trace_occupancy(size_t ldsBytes, int* blocksPerCU) {

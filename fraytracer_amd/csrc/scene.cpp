@@ -296,6 +296,25 @@ struct Flattener {
     }
     FtInstr mk(uint32_t op, uint32_t dst) { FtInstr i{}; i.op = op; i.dst = dst; return i; }
 
+    uint32_t stageEnd = 0;      // constant-pool prefix that must be mirrored in LDS for the fast runs
+
+    // A run of spheres may take the kernel's guarded fast path (kernels.hip: smooth_run_spheres_fast)
+    // when t = strengthInverse * (|c - p| - r) can never exceed the range its exp shortcut is proved
+    // on: finite parameters, strength > 0 and |strengthInverse| * max r <= 80.  Everything else
+    // (lower bound on t, tiny or non-finite |c - p|^2) is checked per evaluation in the kernel.
+    bool fastSphereRun(const HostForm& f, size_t k, size_t run, float strengthInverse) const {
+        if (b.forms[f.kids[k]].kind != HostForm::SPHERE) return false;
+        if (!(f.strength > 0.0f) || !std::isfinite(strengthInverse)) return false;
+        const float a = fabsf(strengthInverse);
+        if (!(a <= 128.0f) || !(a >= 0x1p-20f)) return false;
+        for (size_t j = 0; j < run; ++j) {
+            const std::vector<float>& p = b.forms[f.kids[k + j]].params;
+            for (int c = 0; c < 4; ++c) if (!std::isfinite(p[c])) return false;
+            if (!(p[3] * a <= 80.0f)) return false;
+        }
+        return true;
+    }
+
     // length of the run of consecutive primitives of one type starting at kids[i]
     size_t runLength(const std::vector<int>& kids, size_t i) const {
         const HostForm& f0 = b.forms[kids[i]];
@@ -331,13 +350,17 @@ struct Flattener {
                 if (run > 0) {
                     const HostForm& p0 = b.forms[f.kids[k]];
                     FtInstr i = mk(FT_OP_SMOOTH_RUN, dst); i.type = primType(p0.kind); i.count = (uint32_t)run;
-                    i.data = (uint32_t)out.consts.size(); i.f0 = strengthInverse; i.flags = first ? 1u : 0u;
+                    i.data = (uint32_t)out.consts.size(); i.f0 = strengthInverse; i.flags = first ? FT_FLAG_INIT : 0u;
                     for (size_t j = 0; j < run; ++j) addConsts(b.forms[f.kids[k + j]].params);
+                    if (fastSphereRun(f, k, run, strengthInverse)) {
+                        i.flags |= FT_FLAG_FAST;
+                        stageEnd = (uint32_t)out.consts.size();
+                    }
                     out.instr.push_back(i);
                     k += run;
                 } else {
                     if (!emitForm(f.kids[k], dst + 1)) return false;
-                    FtInstr i = mk(FT_OP_SMOOTH_ADD, dst); i.src = dst + 1; i.f0 = strengthInverse; i.flags = first ? 1u : 0u;
+                    FtInstr i = mk(FT_OP_SMOOTH_ADD, dst); i.src = dst + 1; i.f0 = strengthInverse; i.flags = first ? FT_FLAG_INIT : 0u;
                     out.instr.push_back(i);
                     k += 1;
                 }
@@ -466,6 +489,7 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     Flattener fl(b, out, err);
     if (!fl.emitObject(object, 0)) return false;
     out.nSlots = fl.maxSlot + 1;
+    out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
     for (int i = 0; i < nLights; ++i) {
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
         out.lights.push_back(b.lights[lights[i]].dev);

@@ -83,6 +83,7 @@ struct FlatScene {                                            // host copy of ev
     std::vector<FtLight> lights;
     std::vector<float> materials;
     uint32_t nSlots = 1;
+    uint32_t nStage = 0;                                      // consts[0, nStage) is mirrored in LDS by every workgroup
     uint32_t fastPath = 0;
     float bg[3] = {0, 0, 0};
 };

@@ -121,13 +121,14 @@ bool g_use_libm = false;
 
 __attribute__((target_clones("fma", "default")))
 float orc_expf_impl(float x) {
-    // exp(x) = 2^n * e^r, n = rint(x*log2e), r = x - n*ln2 (two-term), e^r = 1 + r + r^2*q(r),
+    // exp(x) = 2^n * e^r, n = rint(x*log2e) (fused), r = x - n*ln2 (two-term), e^r = 1 + r + r^2*q(r),
     // q = degree-4 fit of (e^r-1-r)/r^2 on |r| <= ln2/2.  Max error ~1.06 ulp; 90.4 % of results
     // are the correctly rounded value (measured against double exp, DESIGN.md "exp/log").
     if (x != x) return x;
     x = x < -104.0f ? -104.0f : (x > 89.0f ? 89.0f : x);             // below: rounds to 0; above: overflows to +inf
-    const float t = x * 0x1.715476p+0f;                              // log2(e)
-    const float n = nearbyintf(t);                                   // round-half-even
+    // n = round-half-even(x*log2e) in ONE rounding: fma onto 1.5*2^23, whose ulp is 1
+    const float tm = __builtin_fmaf(x, 0x1.715476p+0f, 12582912.0f);
+    const float n = tm - 12582912.0f;
     float r = __builtin_fmaf(n, -0x1.62e4p-1f, x);                   // ln2 hi (n*hi exact)
     r = __builtin_fmaf(n, -0x1.7f7d1cp-20f, r);                      // ln2 lo
     float q = 0x1.6d110ap-10f;

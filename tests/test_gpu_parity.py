@@ -47,6 +47,32 @@ def test_math_exp_log_sqrt_div(gpu, oracle):
         assert_bit_equal(gpu.math_eval(3, a, b), a / b, "div")
 
 
+def test_fast_sqrt_exp_exhaustive(gpu):
+    """The guarded fast sqrt / exp of the smooth-union loop equal the exact forms on EVERY float of
+    their guarded ranges (2^-96..2^100 for sqrt, -87..88 for exp): proof by exhaustion, on the GPU."""
+    assert gpu.selftest_fastmath() == {"sqrt": 0, "exp": 0}
+
+
+def test_smooth_union_guard_fallbacks(gpu, oracle):
+    """Points that force the slow path of the smooth-union loop: far away (t < -87, subnormal and zero
+    exponentials, log(0) = -inf -> +inf distance), exactly on a sphere centre (q = 0), huge / non-finite."""
+    scene, _ = syn.config3(n=37)        # 37: exercises the 4-wide blocks and the scalar remainder
+    ds, os_ = both(gpu, oracle, scene)
+    O = oracle.Oracle()
+    form = O.object_form(os_.object)
+    rng = np.random.default_rng(5)
+    centre = np.array(scene.Object.kids[1].kids[0].args[0], np.float32)
+    pts = np.concatenate([
+        rng.uniform(-6, 6, (4000, 3)), rng.uniform(-60, 60, (4000, 3)), rng.uniform(-3000, 3000, (2000, 3)),
+        [centre, centre + np.float32(1e-30), centre + np.float32(1e-12)],
+        [[1e18, 0, 0], [3e38, 3e38, 3e38], [np.inf, 0, 0], [np.nan, 0, 0], [0, 0, 25.9], [0, 0, 21.7], [0, 0, 21.8]],
+    ]).astype(np.float32)
+    d, _ = ds.eval_distance(pts)
+    with np.errstate(all="ignore"):
+        assert_bit_equal(d, O.form_distance(form, pts), "smooth-union distance incl. guard fallbacks")
+    assert np.isinf(d).any() and np.isnan(d).any()
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)

@@ -1,0 +1,34 @@
+"""Condense rocprofv3 CSV output of tools/profile.sh into a short text summary (for profiles/)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                yield f, r
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f, r in rows("trace/**/*kernel_stats.csv"):
+    print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+print("== per-dispatch durations of ft_trace_kernel (ns) ==")
+for f, r in rows("trace/**/*kernel_trace.csv"):
+    if "ft_trace_kernel" in r.get("Kernel_Name", ""):
+        print(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "VGPR", r.get("VGPR_Count"), "SGPR", r.get("SGPR_Count"),
+              "LDS", r.get("LDS_Block_Size"), "grid", r.get("Grid_Size"), "wg", r.get("Workgroup_Size"))
+for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    acc = defaultdict(list)
+    for f, r in rows(f"{name}/**/*counter_collection.csv"):
+        if "ft_trace_kernel" in r.get("Kernel_Name", ""):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if acc:
+        print(f"== {name}: mean per ft_trace_kernel dispatch ==")
+        for k, v in sorted(acc.items()):
+            print(f"{k:28s} {sum(v) / len(v):.6g}   (n={len(v)})")
