@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--spheres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-columns", type=int, default=0,
-                    help="columns of the frame the CPU oracle is timed on (default: 4 per host thread, at least 32)")
+                    help="columns of the frame the CPU oracle is timed on (default: 2 per host thread, at least 32)")
     args = ap.parse_args()
 
     import numpy as np
@@ -141,7 +141,8 @@ def main():
                        "rays_per_frame": rays // args.steps, "primary": rays_primary // args.steps,
                        "shadow": rays_shadow // args.steps, "sdf_evals_per_frame": evals // args.steps,
                        "parallelism": f"column stripes of {STRIPE} over {world} GPU(s) + 1 RCCL gather" if world > 1 else "1 GPU",
-                       "nan_or_cap_flags": flags},
+                       "nan_or_cap_flags": flags,
+                       "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": None,
                          "kernel": "ft_trace_kernel", "kernel_ms": round(launch_s * 1e3, 3),
@@ -163,7 +164,7 @@ def cpu_baseline(scene, cam, W, H, ncols):
     threads = os.cpu_count() or 1
     osc = ob.Oracle().scene(scene)
     if ncols <= 0:
-        ncols = max(32, 4 * threads)          # the oracle's work queue hands out whole columns (Array2D.fs:32)
+        ncols = max(32, 2 * threads)          # the oracle's work queue hands out whole columns (Array2D.fs:32)
     xstep = max(1, W // ncols)
     t0 = time.perf_counter()
     _, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)

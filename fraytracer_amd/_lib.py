@@ -65,7 +65,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_ext", C.c_uint64),
                 ("hits_primary", C.c_uint64), ("hits_shadow", C.c_uint64), ("sdf_evals", C.c_uint64),
-                ("flags", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_float)]
+                ("flags", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_float), ("wave_evals", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

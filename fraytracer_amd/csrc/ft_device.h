@@ -86,7 +86,7 @@ struct FtSceneDev {             // passed by value as kernel argument
 };
 
 struct FtStatsDev {
-    unsigned long long rays_primary, rays_shadow, rays_ext, hits_primary, hits_shadow, sdf_evals, flags, pad;
+    unsigned long long rays_primary, rays_shadow, rays_ext, hits_primary, hits_shadow, sdf_evals, flags, wave_evals;
 };
 
 #define FT_STEP_CAP (1u << 20)  // the reference has no cap (SdfForm.fs:93-104); see DESIGN.md "NaN / step cap"

@@ -29,7 +29,7 @@ hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long lon
                                  unsigned blocks, size_t ldsBytes, hipStream_t st);
 hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
-hipError_t ft_trace_occupancy(size_t ldsBytes, int* blocksPerCU);
+hipError_t ft_trace_occupancy(unsigned fastPath, size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus
 }
 #endif

@@ -116,8 +116,8 @@ __device__ __forceinline__ uint32_t prim_stride(uint32_t type) {
 //   ft_sqrt_fast: q in [2^-96, 2^100].  v_rsq_f32 seed + one coupled Newton step on (s, h) + one
 //                 residual correction: 1 quarter-rate + 7 full-rate ops, no compares/selects
 //                 (hipcc's IEEE sqrtf is ~17 instructions with denormal scaling and fix-ups).
-//   ft_exp_fast:  t in [-87, 88]: the result is normal, so 2^n is applied by adding n to the exponent
-//                 field (v_lshl_add_u32) instead of cvt + v_ldexp_f32 (both half rate), and no clamps.
+//   ft_exp_fast:  t in [-2.9e6, 88]: no NaN test and no clamps; n is taken from the mantissa of the
+//                 magic-number sum (one integer subtract) instead of v_rndne + v_cvt (both half rate).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ft_sqrt_fast(float x) {
     const float r = __builtin_amdgcn_rsqf(x);
@@ -143,21 +143,28 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
     const float r2 = r * r;
     const float sres = fmaf(q, r2, r);
     const float pz = sres + 1.0f;
-    return __uint_as_float((__float_as_uint(tm) << 23) + __float_as_uint(pz));
+    // v_ldexp_f32 rounds subnormal results correctly and flushes to 0 / inf beyond, so no clamps
+    return __builtin_amdgcn_ldexpf(pz, (int)(__float_as_uint(tm) - 0x4B400000u));
 }
 
-#define FT_FAST_T_MIN (-87.0f)
 #define FT_FAST_Q_MIN_BITS 0x0F800000u     // 2^-96
+#define FT_FAST_Q_SPAN_BITS 0x40000000u    // [2^-96, 2^32): one unsigned compare after an OR-tree
+#define FT_FAST_T_LO (-2900000.0f)         // |t * log2e| < 2^22: the magic-number rounding stays exact
+#define FT_FAST_T_HI 88.0f
 
 // sum += exp(si * (|c_i - p| - r_i)) for `count` spheres whose (c, r) records sit in LDS at ldsC
 // (SdfForm.fs:77-80 with sphere children, :129).  Four children per step: their parameter reads are
-// LDS broadcasts (ds_read_b128, no SGPR operands: those halve the VALU rate on gfx950) and their
-// four dependency chains interleave.  The additions into `sum` stay in child order.
+// LDS broadcasts (ds_read_b128; no SGPR operands, which halve the VALU rate on gfx950) and their four
+// dependency chains interleave.  The additions into `sum` stay in child order.
+// Guard: every |c - p|^2 of the block must lie in [2^-96, 2^32) — then ft_sqrt_fast is exact and,
+// with the flatten-time bounds on strength and radii (scene.cpp fastSphereRun), t is inside the
+// range ft_exp_fast is proved on.  NaN / inf / huge / tiny values fail the test and take the exact
+// path; (bits - 2^-96) < 2^30 for all four is tested on the OR of the four differences.
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si, f3 p, float sum) {
     uint32_t i = 0;
     for (; i + 4 <= count; i += 4) {
         float4 prm[4];
-        float q[4], t[4];
+        float q[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) prm[j] = *reinterpret_cast<const float4*>(ldsC + 4 * (i + j));
 #pragma unroll
@@ -165,20 +172,14 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
             const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
             q[j] = (dx * dx + dy * dy) + dz * dz;
         }
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[j] = si * (ft_sqrt_fast(q[j]) - prm[j].w);
-            bad |= !(t[j] >= FT_FAST_T_MIN);                         // also catches NaN / inf / huge q
-        }
-        const uint32_t qmin = min(min(__float_as_uint(q[0]), __float_as_uint(q[1])), min(__float_as_uint(q[2]), __float_as_uint(q[3])));
-        bad |= qmin < FT_FAST_Q_MIN_BITS;                            // q >= +0, so integer order = float order
-        if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
+        const uint32_t span = ((__float_as_uint(q[0]) - FT_FAST_Q_MIN_BITS) | (__float_as_uint(q[1]) - FT_FAST_Q_MIN_BITS)) |
+                              ((__float_as_uint(q[2]) - FT_FAST_Q_MIN_BITS) | (__float_as_uint(q[3]) - FT_FAST_Q_MIN_BITS));
+        if (__builtin_expect(__ballot(span >= FT_FAST_Q_SPAN_BITS) != 0ull, 0)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum = sum + ft_exp(si * (sqrtf(q[j]) - prm[j].w));
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum = sum + ft_exp_fast(t[j]);
+            for (int j = 0; j < 4; ++j) sum = sum + ft_exp_fast(si * (ft_sqrt_fast(q[j]) - prm[j].w));
         }
     }
     for (; i < count; ++i) {
@@ -306,6 +307,23 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
     outLeaf = sl[0];
 }
 
+// Lean evaluator for scenes whose whole program is {fast sphere SMOOTH_RUN..., SMOOTH_FIN, SETLEAF}
+// (FtSceneDev.fastPath == 1, decided when the scene is flattened): the accumulator lives in a VGPR,
+// no value slots, no primitive switch — the kernel variant built on it needs far fewer registers.
+__device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, const f3 p, const float* __restrict__ ldsC,
+                                                       float& outD, uint32_t& outLeaf) {
+    float acc = 0.0f;
+    uint32_t leaf = 0;
+    for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
+        const FtInstr FT_CONST* in = as_const(S.instr) + pc;
+        const uint32_t op = in->op;
+        if (op == FT_OP_SMOOTH_RUN) acc = smooth_run_spheres_fast(ldsC + in->data, in->count, in->f0, p, (in->flags & FT_FLAG_INIT) ? 0.0f : acc);
+        else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log(acc) * in->f0;
+        else leaf = in->aux;                                           // FT_OP_SETLEAF
+    }
+    outD = acc; outLeaf = leaf;
+}
+
 // ------------------------------------------------------------------------------------------------
 // render / trace kernel
 // ------------------------------------------------------------------------------------------------
@@ -419,7 +437,8 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 
 extern __shared__ float ft_lds[];
 
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtRenderArgs a) {
+template <int VARIANT>
+__device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     float* sd = ft_lds + tid;
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + a.S.nSlots * FT_BLOCK) + tid;
@@ -428,6 +447,7 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtR
     __syncthreads();
 
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
+    uint32_t waveEvals = 0;                                            // evaluation rounds of this wave (lane-utilisation statistic)
     bool exhausted = false;
     LaneState s;
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
@@ -460,6 +480,7 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtR
 
         // ---- one scene-SDF evaluation per active lane -----------------------------------------
         const bool active = s.phase >= PH_MARCH && s.phase != PH_LIGHTS;
+        waveEvals += 1;
         if (active) {
             f3 q = s.o;
             if (s.phase >= PH_NX && s.phase <= PH_NC) {                // SdfForm.fs:106-115
@@ -471,7 +492,8 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtR
                 if (s.phase == PH_NZ) q.z = base.z + h;
             }
             float d; uint32_t leaf;
-            ft_eval(a.S, q, sd, sl, ldsC, d, leaf);
+            if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
+            else ft_eval(a.S, q, sd, sl, ldsC, d, leaf);
             s.cEvals += 1;
 
             switch (s.phase) {
@@ -520,9 +542,15 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtR
         atomicAdd(&a.stats->hits_primary, hp);
         atomicAdd(&a.stats->hits_shadow, hs);
         atomicAdd(&a.stats->rays_primary, pr);
+        atomicAdd(&a.stats->wave_evals, (unsigned long long)waveEvals);
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
     }
 }
+
+// general scenes
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtRenderArgs a) { ft_trace_body<0>(a); }
+// scenes that are one smooth union of spheres (BASELINE.json config 3/4)
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres(const FtRenderArgs a) { ft_trace_body<1>(a); }
 
 // scene.Object.Form.Distance at explicit points (test / diagnostic entry)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
@@ -575,7 +603,8 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
 // host-callable launchers (kept in this translation unit so the C ABI file is plain C++)
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
-    hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    if (a->S.fastPath == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    else hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     return hipGetLastError();
 }
 extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
@@ -591,6 +620,7 @@ extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsig
     hipLaunchKernelGGL(ft_selftest_kernel, dim3(4096), dim3(256), 0, st, op, lo, hi, d_mismatches);
     return hipGetLastError();
 }
-extern "C" hipError_t ft_trace_occupancy(size_t ldsBytes, int* blocksPerCU) {
+extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, size_t ldsBytes, int* blocksPerCU) {
+    if (fastPath == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel_smooth_spheres, FT_BLOCK, ldsBytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel, FT_BLOCK, ldsBytes);
 }

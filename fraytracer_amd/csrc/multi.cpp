@@ -126,7 +126,7 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
         for (int r = 0; r < n; ++r) {
             stats->rays_primary += sts[r].rays_primary; stats->rays_shadow += sts[r].rays_shadow; stats->rays_ext += sts[r].rays_ext;
             stats->hits_primary += sts[r].hits_primary; stats->hits_shadow += sts[r].hits_shadow; stats->sdf_evals += sts[r].sdf_evals;
-            stats->flags |= sts[r].flags;
+            stats->flags |= sts[r].flags; stats->wave_evals += sts[r].wave_evals;
             if (sts[r].kernel_ms > stats->kernel_ms) stats->kernel_ms = sts[r].kernel_ms;   // devices run concurrently
         }
     }

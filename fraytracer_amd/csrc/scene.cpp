@@ -306,11 +306,13 @@ struct Flattener {
         if (b.forms[f.kids[k]].kind != HostForm::SPHERE) return false;
         if (!(f.strength > 0.0f) || !std::isfinite(strengthInverse)) return false;
         const float a = fabsf(strengthInverse);
-        if (!(a <= 128.0f) || !(a >= 0x1p-20f)) return false;
+        // the kernel guards |c - p| < 65536, so |t| <= a * (65536 + r) must stay below 2.9e6 (a <= 32,
+        // r <= 1e4) and t <= a * r must stay below 88 (a * r <= 80); r >= 0 keeps t <= a * r.
+        if (!(a <= 32.0f) || !(a >= 0x1p-20f)) return false;
         for (size_t j = 0; j < run; ++j) {
             const std::vector<float>& p = b.forms[f.kids[k + j]].params;
             for (int c = 0; c < 4; ++c) if (!std::isfinite(p[c])) return false;
-            if (!(p[3] * a <= 80.0f)) return false;
+            if (!(p[3] >= 0.0f) || !(p[3] <= 1.0e4f) || !(p[3] * a <= 80.0f)) return false;
         }
         return true;
     }
@@ -490,6 +492,14 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     if (!fl.emitObject(object, 0)) return false;
     out.nSlots = fl.maxSlot + 1;
     out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
+    // kernel variant: 1 = the program is only staged fast sphere runs + SMOOTH_FIN + SETLEAF
+    bool lean = !out.instr.empty();
+    for (const FtInstr& in : out.instr) {
+        if (in.op == FT_OP_SMOOTH_RUN) lean = lean && (in.flags & FT_FLAG_FAST) && in.dst == 0 && in.data + 4u * in.count <= out.nStage;
+        else if (in.op == FT_OP_SMOOTH_FIN || in.op == FT_OP_SETLEAF) lean = lean && in.dst == 0;
+        else lean = false;
+    }
+    out.fastPath = lean ? 1u : 0u;
     for (int i = 0; i < nLights; ++i) {
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
         out.lights.push_back(b.lights[lights[i]].dev);

@@ -80,6 +80,7 @@ typedef struct ft_stats {         /* filled per call; all counts are exact */
     uint64_t flags;               /* bit0 NaN distance met, bit2 step cap hit (reference would not terminate) */
     float kernel_ms;              /* HIP-event time of the render kernel(s) of this call */
     float reserved;
+    uint64_t wave_evals;          /* wave-level evaluation rounds: sdf_evals / (64 * wave_evals) = lane utilisation */
 } ft_stats;
 
 /* ---- context ------------------------------------------------------------------------ */
