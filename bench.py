@@ -58,6 +58,7 @@ def main():
 
     import fraytracer_amd as ft
     from fraytracer_amd import synthetic as syn
+    from fraytracer_amd import distributed as ftd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,15 +87,12 @@ def main():
     slab = torch.empty((cols, H, 3), dtype=torch.float32, device="cuda")
     gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
     frame = torch.empty((W, H, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
-    tiling = dict(stripe_width=STRIPE, stripe_ranks=world, stripe_rank=rank, n_columns=cols) if world > 1 else {}
+    tiling = ftd.tiling(W, world, rank, STRIPE)
 
     def step():
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
-        if world > 1:
-            dist.gather(slab, gathered, dst=0)    # the ONE collective of the path (RCCL over xGMI)
-            if rank == 0:                         # stripe j of rank r -> columns [(j*world + r)*STRIPE, +STRIPE)
-                g = torch.stack(gathered).view(world, cols // STRIPE, STRIPE, H, 3)
-                frame.view(cols // STRIPE, world, STRIPE, H, 3).copy_(g.permute(1, 0, 2, 3, 4))
+        if world > 1:                             # ONE RCCL gather over xGMI + de-interleave on rank 0
+            ftd.gather_frame(slab, world, rank, STRIPE, frame=frame, gathered=gathered)
 
     def fence():
         if world > 1:

@@ -297,6 +297,17 @@ struct Flattener {
     FtInstr mk(uint32_t op, uint32_t dst) { FtInstr i{}; i.op = op; i.dst = dst; return i; }
 
     uint32_t stageEnd = 0;      // constant-pool prefix that must be mirrored in LDS for the fast runs
+    std::vector<int> matRemap;  // context-wide material handle -> dense index in this scene's table
+
+    uint32_t matIndex(int handle) {
+        if (matRemap.empty()) matRemap.assign(b.materials.size(), -1);
+        if (matRemap[handle] < 0) {
+            matRemap[handle] = (int)(out.materials.size() / 3);
+            const f3& m = b.materials[handle];
+            out.materials.push_back(m.x); out.materials.push_back(m.y); out.materials.push_back(m.z);
+        }
+        return (uint32_t)matRemap[handle];
+    }
 
     // A run of spheres may take the kernel's guarded fast path (kernels.hip: smooth_run_spheres_fast)
     // when t = strengthInverse * (|c - p| - r) can never exceed the range its exp shortcut is proved
@@ -422,7 +433,7 @@ struct Flattener {
             const bool solidPrim = kf.isPrim() && (ko < 0 || b.objects[ko].kind == HostObject::CREATE);
             if (solidPrim) {
                 c.type = primType(kf.kind); c.data = addConsts(kf.params);
-                c.mat = ko >= 0 ? (uint32_t)b.objects[ko].material : 0u;
+                c.mat = ko >= 0 ? matIndex(b.objects[ko].material) : 0u;
             } else {
                 if (nextSlot >= FT_MAX_SLOTS) return fail("union has more combinator children than FT_MAX_SLOTS value slots");
                 if (ko >= 0 ? !emitObject(ko, nextSlot) : !emitForm(f.kids[k], nextSlot)) return false;
@@ -461,7 +472,7 @@ struct Flattener {
         switch (o.kind) {
         case HostObject::CREATE: {
             if (!emitForm(o.form, dst)) return false;
-            FtInstr i = mk(FT_OP_SETLEAF, dst); i.aux = (uint32_t)o.material;
+            FtInstr i = mk(FT_OP_SETLEAF, dst); i.aux = matIndex(o.material);
             out.instr.push_back(i);
             return true;
         }
@@ -504,7 +515,7 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
         out.lights.push_back(b.lights[lights[i]].dev);
     }
-    for (const f3& m : b.materials) { out.materials.push_back(m.x); out.materials.push_back(m.y); out.materials.push_back(m.z); }
+    if (out.materials.empty()) { out.materials.assign(3, 0.0f); }           // a form-only union under no create(): index 0 must exist
     out.bg[0] = bg[0]; out.bg[1] = bg[1]; out.bg[2] = bg[2];
     if (out.cellStart.empty()) out.cellStart.push_back(0);
     // keep every pool non-empty and padded so device-side wide loads never run off the end

@@ -1,0 +1,47 @@
+"""Multi-GPU tiling of Image.render: interleaved column stripes + ONE gather.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU in
+tests).  Pixels are independent (Image.fs:28-35), so ranks share nothing while rendering; the only
+exchange is the collection of the finished column slabs on rank 0.  Because FColor[X,Y] is x-major
+(Array2D.fs:30-38) a stripe of S columns is one contiguous run of S*H*3 floats both in a rank's slab
+and in the final frame.
+"""
+import torch
+import torch.distributed as dist
+
+
+def stripe_columns(width, world, rank, stripe):
+    """Image columns rendered by `rank`, in slab order — the mapping of ft_render_params:
+    x = (c // S) * S * world + rank * S + c % S  for local column c."""
+    if width % (stripe * world) != 0:
+        raise ValueError(f"width {width} must be a multiple of stripe {stripe} x world {world}")
+    cols = width // world
+    return [(c // stripe) * stripe * world + rank * stripe + c % stripe for c in range(cols)]
+
+
+def tiling(width, world, rank, stripe):
+    """keyword arguments for DeviceScene.render / render_device describing this rank's share"""
+    if world == 1:
+        return {}
+    if width % (stripe * world) != 0:
+        raise ValueError(f"width {width} must be a multiple of stripe {stripe} x world {world}")
+    return dict(stripe_width=stripe, stripe_ranks=world, stripe_rank=rank, n_columns=width // world)
+
+
+def gather_frame(slab, world, rank, stripe, frame=None, gathered=None, group=None):
+    """Collect the per-rank slabs [W/world, H, 3] on rank 0 and de-interleave them into the full
+    [W, H, 3] frame.  Returns the frame on rank 0, None elsewhere.  `frame` / `gathered` may be
+    pre-allocated buffers (bench.py reuses them across steps)."""
+    if world == 1:
+        return slab
+    cols, H, C = slab.shape
+    if rank == 0 and gathered is None:
+        gathered = [torch.empty_like(slab) for _ in range(world)]
+    dist.gather(slab, gathered if rank == 0 else None, dst=0, group=group)      # the ONE collective of the path
+    if rank != 0:
+        return None
+    if frame is None:
+        frame = torch.empty((cols * world, H, C), dtype=slab.dtype, device=slab.device)
+    g = torch.stack(gathered).view(world, cols // stripe, stripe, H, C)          # [rank, stripe j, s, y, c]
+    frame.view(cols // stripe, world, stripe, H, C).copy_(g.permute(1, 0, 2, 3, 4))
+    return frame

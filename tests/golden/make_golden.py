@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.  The reference ships no fixtures and cannot run here (no .NET), so
+these vectors are OUTPUTS OF THE CPU ORACLE (oracle/ft_oracle.cpp) on the synthetic configs: they pin
+the oracle against regressions and give the GPU tests fixed data — they are NOT outputs of the F#
+program ("parity unpinned").  Each file holds the float32 image [X, Y, 3], the exact ray /
+hit counters and the render parameters.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from fraytracer_amd import synthetic as syn   # noqa: E402
+from oracle import binding as ob               # noqa: E402
+
+CASES = {
+    "c1_sphere_64": (lambda: syn.config1()[0], 64, 64),
+    "c2_union32_64": (lambda: syn.config2()[0], 64, 64),
+    "c2_union32_boxes_64": (lambda: syn.config2(boxes=True)[0], 64, 64),
+    "c3_smooth256_48": (lambda: syn.config3()[0], 48, 48),
+    "console_like_300_64": (lambda: syn.console_like(n=300)[0], 64, 64),
+    "mixed_nested_48x40": (lambda: syn.mixed_nested()[0], 48, 40),
+}
+
+
+def render(name):
+    make, W, H = CASES[name]
+    cam = syn.default_camera().as_array()
+    img, cnt = ob.Oracle().scene(make()).render(syn.EPSILON, syn.RAY_LENGTH, W, H, cam, nthreads=4)
+    counts = np.array([cnt[k] for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "flags")], np.int64)
+    return img, counts, np.array([W, H], np.int32)
+
+
+if __name__ == "__main__":
+    for name in CASES:
+        img, counts, size = render(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, counts=counts, size=size,
+                            epsilon=np.float32(syn.EPSILON), length=np.float32(syn.RAY_LENGTH))
+        print(name, img.shape, counts.tolist())

@@ -1,0 +1,103 @@
+"""libfraytracer_hip's host side (scene construction + flattening, no GPU) against the oracle:
+boundaries and the uniform grids must agree bit for bit, the flattened program must have the
+documented shape.  Uses a host-only context (device -1); nothing here launches a kernel."""
+import numpy as np
+import pytest
+
+import fraytracer_amd as ft
+from fraytracer_amd import synthetic as syn
+from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+
+
+@pytest.fixture(scope="module")
+def host():
+    d = ft.Device(-1)
+    yield d
+    d.close()
+
+
+def all_forms(scene):
+    out, seen = [], set()
+
+    def walk(n):
+        if id(n) in seen: return
+        seen.add(id(n))
+        if isinstance(n, ft.api.Form): out.append(n)
+        for k in n.kids: walk(k)
+    walk(scene.Object)
+    return out
+
+
+@pytest.mark.parametrize("make", [lambda: syn.config2()[0], lambda: syn.config2(boxes=True)[0], lambda: syn.config3(n=50)[0],
+                                  lambda: syn.console_like(n=150)[0], lambda: syn.mixed_nested()[0]])
+def test_boundaries_match_oracle_bitwise(host, oracle, make):
+    scene = make()
+    O = oracle.Oracle()
+    mh, mo = {}, {}
+    ft.realise(scene.Object, host, mh)
+    ft.realise(scene.Object, O, mo)
+    forms = all_forms(scene)
+    assert len(forms) > 3
+    for f in forms:
+        a = np.array(host.form_boundary(mh[id(f)]), np.float32)
+        b = np.array(O.form_boundary(mo[id(f)]), np.float32)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, a, b)
+
+
+@pytest.mark.parametrize("make", [lambda: syn.config2()[0], lambda: syn.console_like(n=400)[0],
+                                  lambda: syn.console_like(seed=3, n=80, factory=syn.random_triangle)[0]])
+def test_grid_matches_oracle_bitwise(host, oracle, make):
+    scene = make()
+    ds = host.scene(scene)
+    info = ds.info()
+    assert info["n_grids"] == 1
+    g = ds.grid(0)
+    O = oracle.Oracle()
+    memo = {}
+    obj = ft.realise(scene.Object, O, memo)
+    # the (object) union is the innermost object of subtract(intersect(union, ..), ..) or the root itself
+    node = scene.Object
+    while node.kind != "union":
+        node = node.kids[0]
+    og = O.grid(O.object_form(memo[id(node)]))
+    assert g["counts"] == og["counts"]
+    for k in ("aabbMin", "cellSizeInv"):
+        assert np.array_equal(g[k].view(np.uint32), og[k].view(np.uint32)), k
+    assert np.array_equal(g["cell_start"], og["cell_start"])
+    assert np.array_equal(g["centers"].view(np.uint32), og["centers"].view(np.uint32))
+    assert np.array_equal(g["lower"].view(np.uint32), og["lower"].view(np.uint32))
+    assert np.array_equal(g["child"], og["child"])
+    ds.close()
+
+
+def test_flattened_program_shapes(host):
+    # C3: one staged fast sphere run + FIN + SETLEAF -> lean kernel variant, one value slot
+    i = host.scene(syn.config3()[0]).info()
+    assert (i["n_instr"], i["n_slots"], i["fast_path"], i["n_grids"]) == (3, 1, 1, 0)
+    # console scene: UNION, ISECT_RUN(sphere), PRIM(sphere), SUBTRACT -> general kernel, two slots, 1000 children
+    i = host.scene(syn.console_like(n=1000)[0]).info()
+    assert (i["n_instr"], i["n_slots"], i["fast_path"], i["n_grids"], i["n_children"], i["n_materials"]) == (4, 2, 0, 1, 1000, 1000)
+    # strength outside the proven range of the fast exp disables the fast path, not the scene
+    forms = [SdfForm.Primitive.sphere((x, 0, 0), 0.5) for x in range(4)]
+    tiny = SdfScene(SdfObject.create(SdfMaterial.createSolid((1, 1, 1)), SdfForm.unionSmooth(0.001, forms)), syn.BACKGROUND)
+    assert host.scene(tiny).info()["fast_path"] == 0
+    # mixed primitive kinds in a smooth union: one run per kind in child order
+    mixed = SdfScene(SdfObject.create(SdfMaterial.createSolid((1, 1, 1)), SdfForm.unionSmooth(0.25, [
+        forms[0], forms[1], SdfForm.Primitive.capsule((0, 1, 0), (1, 1, 0), 0.2), forms[2]])), syn.BACKGROUND)
+    assert host.scene(mixed).info()["n_instr"] == 5          # RUN(2 spheres), RUN(capsule), RUN(sphere), FIN, SETLEAF
+
+
+def test_nested_unions_use_extra_slots(host):
+    i = host.scene(syn.mixed_nested()[0]).info()
+    assert i["n_grids"] == 3 and i["n_slots"] >= 3 and i["fast_path"] == 0
+
+
+def test_errors_are_reported_not_swallowed(host):
+    with pytest.raises(ft.FrayTracerError) as e:
+        host.form_union([])
+    assert e.value.code == ft._lib.FT_ERR_EMPTY and "No SdfObjects given" in str(e.value)       # SdfForm.fs:16
+    with pytest.raises(ft.FrayTracerError):
+        host.form_subtract(12345, 0)
+    with pytest.raises(ft.FrayTracerError) as e:
+        host.scene(syn.config1()[0]).render(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera())
+    assert e.value.code == ft._lib.FT_ERR_NO_DEVICE                                             # no CPU fallback

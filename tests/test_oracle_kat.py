@@ -1,0 +1,232 @@
+"""Known answers that pin the CPU oracle.  The reference ships no tests or golden vectors
+ and cannot be built here, so these are hand-derived from the F# text; every expected
+value below is computed independently of oracle/ft_oracle.cpp (numpy float32 or closed form)."""
+import numpy as np
+import pytest
+
+import fraytracer_amd as ft
+from fraytracer_amd import synthetic as syn
+from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfLight, SdfScene
+
+F = np.float32
+EPS, LEN = syn.EPSILON, syn.RAY_LENGTH
+PI_INV = F(1) / F(3.14159274)                     # Math.fs:28-30
+
+
+def sphere_scene(lights=(), color=(0.8, 0.8, 0.8)):
+    obj = SdfObject.create(SdfMaterial.createSolid(color), SdfForm.Primitive.sphere((0, 0, 0), 1.0))
+    return SdfScene(obj, syn.BACKGROUND, lights)
+
+
+def centre_ray():
+    return np.array([[0, 0, -10, 0, 0, 1, LEN, EPS]], F)
+
+
+def test_camera_matches_closed_form(oracle):
+    # Camera.fs:33-42 with Program.fs:16-22: forward (0,0,1), right (1,0,0), up (0,1,0), all scaled by
+    # Lens.create 60.0f = sin(30 rad) (radians!) = -0.98803162
+    cam = oracle.camera_lookat((0, 0, -10), (0, 0, 0), (0, 1, 0), oracle.lens_create(60.0))
+    nps = F(np.sin(np.float64(F(60.0) * F(0.5))))
+    assert nps == F(-0.98803162)
+    np.testing.assert_array_equal(cam[0:6], np.array([0, 0, -10, 0, 0, 1], F))
+    assert cam[7] == nps and cam[9] == nps                    # UpScaled.y, RightScaled.x
+    assert np.all(cam[[6, 8, 10, 11]] == 0)
+    # product's host code agrees bit for bit
+    np.testing.assert_array_equal(syn.default_camera().as_array().view(np.uint32), cam.view(np.uint32))
+
+
+def test_centre_pixel_ray_is_exactly_forward(oracle):
+    # Image.fs:17-23,30: pixel position = x / max(W,H), no +0.5; x = N/2 -> 0.5 -> direction (0,0,1)
+    cam = syn.default_camera().as_array()
+    r = oracle.pixel_ray(cam, 256, 256, 128, 128, EPS, LEN)
+    np.testing.assert_array_equal(r, np.array([0, 0, -10, 0, 0, 1, LEN, EPS], F))
+
+
+def test_miss_returns_background_exactly(oracle):
+    O = oracle.Oracle()
+    sc = O.scene(sphere_scene())
+    out, cnt = sc.trace_rays(np.array([[0, 5, -10, 0, 0, 1, LEN, EPS], [0, 0, -10, 0, 0, 1, 0.0, EPS]], F))
+    np.testing.assert_array_equal(out, np.tile(F(syn.BACKGROUND), (2, 1)))       # SdfScene.fs:10; Length<=0 -> miss
+    assert cnt["hits_primary"] == 0
+
+
+def test_centre_pixel_two_steps_then_hit_no_lights(oracle):
+    # d = 10 - 1 = 9 -> origin (0,0,-1), Length 21; d = 0 < eps -> hit.
+    # 2 march evals + 4 normal probes = 6 Distance calls, 1 Ray.move.  Colour = Color * (bg * 1/pi).
+    O = oracle.Oracle()
+    out, cnt = O.scene(sphere_scene()).trace_rays(centre_ray())
+    assert cnt["root_evals"] == 6 and cnt["march_steps"] == 1 and cnt["hits_primary"] == 1
+    want = F(0.8) * (F(0.1) * PI_INV)
+    np.testing.assert_array_equal(out[0], np.array([want] * 3, F))
+
+
+def test_pulled_back_hit_point_shadows_itself(oracle):
+    # SURVEY.md §7 worked example: hit origin (0,0,-1) is pulled back by eps to z = -1.00999999046;
+    # a shadow ray from there sees d = 0.00999999046 < 0.01f = 0.00999999978 -> "hit" on its first
+    # evaluation, so a light shining straight at the surface contributes nothing.
+    z = F(-1) + F(1) * F(-EPS)
+    assert F(-z - F(1)) < F(EPS)
+    O = oracle.Oracle()
+    light = SdfLight.directional((0, 0, 1), (5, 5, 5))                       # normalize(-dir) = (0,0,-1) = the normal
+    out, cnt = O.scene(sphere_scene([light])).trace_rays(centre_ray())
+    assert cnt["rays_shadow"] == 1 and cnt["hits_shadow"] == 1
+    np.testing.assert_array_equal(out[0], np.array([F(0.8) * (F(0.1) * PI_INV)] * 3, F))
+
+
+def test_light_from_behind_casts_no_shadow_ray(oracle):
+    O = oracle.Oracle()
+    out, cnt = O.scene(sphere_scene([SdfLight.directional((0, 0, -1), (5, 5, 5))])).trace_rays(centre_ray())
+    assert cnt["rays_shadow"] == 0                                           # lightCos <= 0 (SdfScene.fs:17)
+
+
+def test_point_light_shadow_ray_covers_one_world_unit(oracle):
+    # SdfLight.fs:27-37: Direction = diff / |diff|^2 (not unit) with Length = |diff|, so the shadow march
+    # advances at most |diff| * |Direction| = 1 world unit.  An occluder 1.7 units along the way to the
+    # light is therefore never reached: the reference lights the pixel.  Reproduced, not fixed.
+    big = SdfObject.create(SdfMaterial.createSolid((0.8, 0.8, 0.8)), SdfForm.Primitive.sphere((0, 0, 0), 1.0))
+    occluder = SdfObject.create(SdfMaterial.createSolid((0.1, 0.9, 0.1)), SdfForm.Primitive.sphere((0, 1.5, -2.5), 0.4))
+    light = SdfLight.point((0, 3, -4), (10, 0, 0))
+    O = oracle.Oracle()
+    # start 0.005 above the surface: the first evaluation already "hits" (d = 0.005 < eps) with d > 0, so
+    # the pulled-back point (z = -1.015, d = 0.015 >= eps) is NOT self-shadowed (unlike the centre pixel)
+    ray = np.array([[0, 0, -1.005, 0, 0, 1, LEN, EPS]], F)
+    lit, cnt = O.scene(SdfScene(SdfObject.union([big, occluder]), syn.BACKGROUND, [light])).trace_rays(ray)
+    assert cnt["rays_shadow"] == 1 and cnt["hits_shadow"] == 0
+    unlit = F(0.8) * (F(0.1) * PI_INV)
+    assert lit[0, 0] > unlit and lit[0, 1] == unlit and lit[0, 2] == unlit   # red light only; material of the big sphere
+    # intensity = color / distance2 * lightCos with the TRUE unit direction for the cosine (SdfLight.fs:25,40)
+    hp = np.array([0, 0, F(-1.005) + F(-EPS)], F)
+    diff = np.array([0, 3, -4], F) - hp
+    d2 = F(F(diff[0] * diff[0] + diff[1] * diff[1]) + diff[2] * diff[2])
+    ldir = diff / np.sqrt(d2)
+
+    def dist(q):                                                            # sphere r=1 at the origin, float32 throughout
+        return F(np.sqrt(F(F(q[0] * q[0] + q[1] * q[1]) + q[2] * q[2])) - F(1))
+    h = F(EPS) * F(0.125)                                                   # SdfForm.fs:114-115 forward differences at hp
+    g = np.array([dist(hp + np.array([h, 0, 0], F)), dist(hp + np.array([0, h, 0], F)), dist(hp + np.array([0, 0, h], F))], F) - dist(hp)
+    nrm = g / np.sqrt(F(F(g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]))
+    cos = F(F(nrm[0] * ldir[0] + nrm[1] * ldir[1]) + nrm[2] * ldir[2])
+    assert abs(float(lit[0, 0]) - float(F(0.8) * F((F(0.1) + F(10) / d2 * cos) * PI_INV))) < 1e-7
+
+
+def test_boundary_union_and_intersection_quirk(oracle):
+    O = oracle.Oracle()
+    a = SdfForm.Primitive.sphere((0, 0, 0), 2.0)
+    b = SdfForm.Primitive.sphere((3, 0, 0), 2.0)
+    # union (SdfBoundary.fs:7-22): a' = (-2,0,0), b' = (5,0,0) -> centre (1.5,0,0), radius 3.5
+    u = ft.realise(SdfForm.unionSmooth(0.25, [a, b]), O)
+    assert O.form_boundary(u) == (1.5, 0.0, 0.0, 3.5)
+    # containment branches
+    c = ft.realise(SdfForm.unionSmooth(0.25, [a, SdfForm.Primitive.sphere((0.5, 0, 0), 1.0)]), O)
+    assert O.form_boundary(c) == (0.0, 0.0, 0.0, 2.0)
+    # intersection (SdfBoundary.fs:29-49): the reference forgets to square (d2 - bR2 + aR2):
+    # sqrt(4*9*4 - (9 - 4 + 4)) / 6 = sqrt(135)/6, not sqrt(144 - 81)/6
+    i = ft.realise(SdfForm.intersect([a, b]), O)
+    cx, cy, cz, r = O.form_boundary(i)
+    assert (cx, cy, cz) == (1.5, 0.0, 0.0)
+    assert F(r) == F(np.sqrt(F(135.0))) / F(6.0)
+    assert F(r) != F(np.sqrt(F(63.0))) / F(6.0)
+
+
+def test_grid_counts_use_x_extent_on_all_axes(oracle):
+    # SdfBoundary.fs:237-239: countX/Y/Z all from aabbSize.X.  Two unit spheres at (0,0,0), (6,1,0):
+    # aabb (8,3,2), countSize 1.5 -> ceil(8/1.5) = 6 on every axis (Y would be 2, Z 2 if it used its own extent)
+    O = oracle.Oracle()
+    u = ft.realise(SdfForm.union([SdfForm.Primitive.sphere((0, 0, 0), 1.0), SdfForm.Primitive.sphere((6, 1, 0), 1.0)]), O)
+    g = O.grid(u)
+    assert g["counts"] == (6, 6, 6)
+    np.testing.assert_array_equal(g["aabbMin"], np.array([-1, -1, -1], F))
+    np.testing.assert_array_equal(g["cellSize"], np.array([8, 3, 2], F) / F(6))
+    # every cell lists at least one candidate, lists are sorted by LowerBound (SdfBoundary.fs:267-268)
+    cs = g["cell_start"]
+    assert np.all(np.diff(cs.astype(np.int64)) >= 1)
+    for c in range(len(cs) - 1):
+        lb = g["lower"][cs[c]:cs[c + 1]]
+        assert np.all(np.diff(lb) >= 0)
+
+
+def test_primitive_distances_closed_form(oracle):
+    O = oracle.Oracle()
+    s = ft.realise(SdfForm.Primitive.sphere((1, 2, 3), 0.5), O)
+    assert O.form_distance(s, [[1, 2, 7]])[0] == F(3.5)
+    cap = ft.realise(SdfForm.Primitive.capsule((0, 0, 0), (4, 0, 0), 0.5), O)
+    np.testing.assert_array_equal(O.form_distance(cap, [[-3, 0, 0], [2, 2, 0], [7, 4, 0]]), np.array([2.5, 1.5, 4.5], F))
+    assert O.form_boundary(cap) == (2.0, 0.0, 0.0, 2.5)                      # Lerp midpoint, r + |To-From|/2
+    tor = ft.realise(SdfForm.Primitive.torus((0, 0, 0), (0, 0, 2), 2.0, 0.5), O)   # normal is re-normalised (SdfForm.fs:182)
+    np.testing.assert_array_equal(O.form_distance(tor, [[2, 0, 0], [0, 0, 0], [2, 0, 3]]), np.array([-0.5, 1.5, 2.5], F))
+    assert O.form_boundary(tor) == (0.0, 0.0, 0.0, 2.5)
+    tri = ft.realise(SdfForm.Primitive.triangle((0, 0, 0), (4, 0, 0), (0, 4, 0), 0.25), O)
+    d = O.form_distance(tri, [[1, 1, 2], [1, 1, -3], [-3, 0, 0], [1, -2, 0]])
+    np.testing.assert_array_equal(d, np.array([1.75, 2.75, 2.75, 1.75], F))     # face, face, vertex edge, edge
+    cx, cy, cz, r = O.form_boundary(tri)                                     # circumcentre (2,2,0), circumradius sqrt(8) + r
+    assert (cx, cy, cz) == (2.0, 2.0, 0.0) and abs(r - (np.sqrt(8.0) + 0.25)) < 1e-6
+
+
+def test_combinator_semantics(oracle):
+    O = oracle.Oracle()
+    a = SdfForm.Primitive.sphere((0, 0, 0), 2.0)
+    b = SdfForm.Primitive.sphere((1, 0, 0), 1.0)
+    p = [[3.0, 0.0, 0.0], [0.5, 0.0, 0.0], [-1.5, 0.0, 0.0]]
+    da, db = np.array([1.0, -1.5, -0.5], F), np.array([1.0, -0.5, 1.5], F)
+    np.testing.assert_array_equal(O.form_distance(ft.realise(SdfForm.subtract(a, b), O), p), np.maximum(-db, da))     # SdfForm.fs:46-47
+    np.testing.assert_array_equal(O.form_distance(ft.realise(SdfForm.intersect([a, b]), O), p), np.maximum(da, db))
+    np.testing.assert_array_equal(O.form_distance(ft.realise(SdfForm.union([a, b]), O), p), np.minimum(da, db))
+    # unionSmooth (SdfForm.fs:75-82): -log(sum exp(-d/k)) * k
+    k = 0.25
+    got = O.form_distance(ft.realise(SdfForm.unionSmooth(k, [a, b]), O), p)
+    want = -np.log(np.exp(-da.astype(np.float64) / k) + np.exp(-db.astype(np.float64) / k)) * k
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-7)
+    # far from everything every exp underflows: log 0 = -inf -> distance +inf -> the march ends as a miss
+    far = O.form_distance(ft.realise(SdfForm.unionSmooth(k, [a, b]), O), [[0, 0, 40.0]])
+    assert np.isposinf(far[0])
+
+
+def test_single_child_combinators_return_the_child():
+    s = SdfForm.Primitive.sphere((0, 0, 0), 1.0)
+    assert SdfForm.union([s]) is s and SdfForm.intersect([s]) is s and SdfForm.unionSmooth(0.25, [s]) is s   # SdfForm.fs:17,54,72
+    o = SdfObject.create(SdfMaterial.createSolid((1, 1, 1)), s)
+    assert SdfObject.union([o]) is o                                                                        # SdfObject.fs:15
+    with pytest.raises(ValueError):
+        SdfForm.union([])
+
+
+def test_object_union_material_is_argmin_with_first_wins_ties(oracle):
+    O = oracle.Oracle()
+    red = SdfObject.create(SdfMaterial.createSolid((1, 0, 0)), SdfForm.Primitive.sphere((-1, 0, 0), 1.0))
+    green = SdfObject.create(SdfMaterial.createSolid((0, 1, 0)), SdfForm.Primitive.sphere((1, 0, 0), 1.0))
+    u = ft.realise(SdfObject.union([red, green]), O)
+    assert O.object_color(u, (-0.9, 0.3, 0)) == (1.0, 0.0, 0.0)
+    assert O.object_color(u, (0.7, 0.1, 0)) == (0.0, 1.0, 0.0)
+    # equidistant point: strict '<' (SdfObject.fs:41) keeps the first candidate of the cell's sorted list
+    assert O.object_color(u, (0.0, 0.5, 0)) in ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    # subtract / intersect keep the first object's material (SdfObject.fs:50-64)
+    s = ft.realise(SdfObject.subtract(red, SdfForm.Primitive.sphere((5, 5, 5), 1.0)), O)
+    assert O.object_color(s, (9, 9, 9)) == (1.0, 0.0, 0.0)
+
+
+def test_oracle_exp_log_accuracy(oracle):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-104, 88.7, 400000), rng.uniform(-1, 1, 100000)]).astype(F)
+    got = oracle.expf(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    ulp = np.spacing(ref.astype(F)).astype(np.float64)
+    ok = ref > 1e-37
+    assert np.max(np.abs(got - ref)[ok] / ulp[ok]) < 1.1          # stated bound: ~1.06 ulp (DESIGN.md "exp/log")
+    assert np.mean(got.astype(F)[ok] == ref.astype(F)[ok]) > 0.89
+    u = rng.integers(1, 0x7F800000, 500000, dtype=np.uint32).view(F)
+    gl = oracle.logf(u).astype(np.float64)
+    rl = np.log(u.astype(np.float64))
+    ulpl = np.spacing(np.abs(rl.astype(F))).astype(np.float64)
+    assert np.max(np.abs(gl - rl) / np.maximum(ulpl, 1e-45)) < 0.51   # correctly rounded up to double-rounding ties
+    assert oracle.expf(np.array([-200, 100, np.nan, -np.inf, np.inf], F)).tolist()[:2] == [0.0, np.inf]
+    sp = oracle.logf(np.array([0.0, -1.0, np.inf, 1.0], F))
+    assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and sp[3] == 0.0
+
+
+def test_mathf_min_max_semantics(oracle):
+    # .NET Core 3.0+ MathF.Min/Max: NaN propagates, -0 < +0
+    lib = oracle.lib
+    assert np.isnan(lib.orc_mathf_min(1.0, float("nan"))) and np.isnan(lib.orc_mathf_max(float("nan"), 1.0))
+    assert np.signbit(lib.orc_mathf_min(0.0, -0.0)) and np.signbit(lib.orc_mathf_min(-0.0, 0.0))
+    assert not np.signbit(lib.orc_mathf_max(0.0, -0.0)) and not np.signbit(lib.orc_mathf_max(-0.0, 0.0))
+    assert lib.orc_mathf_min(2.0, 3.0) == 2.0 and lib.orc_mathf_max(2.0, 3.0) == 3.0
