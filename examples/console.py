@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""The reference's console program (src/FrayTracer.Console/Program.fs) on the MI355X path:
+System.Random(19) scene of 1000 tori, 1000x1000, epsilon 0.01, ray length 30, timing line, result.bmp.
+
+    python examples/console.py [--size 1000] [--tori 1000] [--out result.bmp]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import fraytracer_amd as ft
+from fraytracer_amd import synthetic as syn
+from fraytracer_amd.dotnet_random import Random
+from fraytracer_amd.postprocess import toColors, saveBitmap
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=1000)
+ap.add_argument("--tori", type=int, default=1000)
+ap.add_argument("--out", default="result.bmp")
+args = ap.parse_args()
+
+scene, _ = syn.console_scene(seed=19, n=args.tori, size=args.size)        # Program.fs:14-83
+camera = syn.default_camera()                                              # Program.fs:16-22
+imageSize = ft.ImageSize(args.size, args.size)
+epsilon = 0.01                                                             # Program.fs:85
+
+print("Rendering...")                                                      # Program.fs:87
+t0 = time.perf_counter()
+traced = ft.Image.render(epsilon, 30.0, imageSize, camera, ft.SdfScene.trace(scene))   # Program.fs:90-93
+print(f"Time = {time.perf_counter() - t0:.2f} sec")                        # Program.fs:96 (includes scene upload)
+
+rng = Random(19)   # the reference keeps drawing from the scene's generator; its dithering is racy anyway
+saveBitmap(args.out, toColors(2.2, rng if args.size <= 256 else None, traced))          # Program.fs:98-100
+print("wrote", args.out)

@@ -6,7 +6,7 @@ Importing it fails if the shared library has not been built; there is no CPU fal
 """
 from ._lib import FrayTracerError, LIB_PATH
 from .api import (FColor, SdfForm, SdfMaterial, SdfObject, SdfLight, SdfScene, Lens, Camera, ImageSize, Image,
-                  Device, DeviceScene, SceneTrace, realise)
+                  Device, DeviceScene, SceneTrace, realise, render_multi)
 
 __all__ = ["FColor", "SdfForm", "SdfMaterial", "SdfObject", "SdfLight", "SdfScene", "Lens", "Camera", "ImageSize",
-           "Image", "Device", "DeviceScene", "SceneTrace", "realise", "FrayTracerError", "LIB_PATH"]
+           "Image", "Device", "DeviceScene", "SceneTrace", "realise", "render_multi", "FrayTracerError", "LIB_PATH"]

@@ -386,6 +386,32 @@ class DeviceScene:
         return d, m
 
 
+def render_multi(devices, scene, epsilon, length, imageSize, camera, stripe_width=16):
+    """ft_render_multi: single-process multi-GPU render (one host thread + context per device inside the
+    library, column stripes, ONE ncclGather to devices[0], de-interleave on the way to the host).
+    Returns (float32 [X, Y, 3], stats)."""
+    scenes = [devices[0].scene(scene)]
+    for d in devices[1:]:
+        p = C.c_void_p()
+        check(lib.ft_scene_clone(scenes[0]._scene, d._ctx, C.byref(p)))
+        clone = DeviceScene.__new__(DeviceScene)
+        clone.device, clone._scene = d, p
+        scenes.append(clone)
+    n = len(devices)
+    ctxs = (C.c_void_p * n)(*[d._ctx for d in devices])
+    scs = (C.c_void_p * n)(*[s._scene for s in scenes])
+    W, H = int(imageSize.X), int(imageSize.Y)
+    p = _lib.RenderParams(W, H, 0, W, int(stripe_width), 1, 0, 1, float(epsilon), float(length), 0, 0.0)
+    out = np.empty((W, H, 3), np.float32)
+    st = _lib.Stats()
+    try:
+        check(lib.ft_render_multi(ctxs, scs, n, C.byref(camera._c), C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+    finally:
+        for s in scenes[1:]:
+            s.close()
+    return out, st.as_dict()
+
+
 class SceneTrace:
     """The value `SdfScene.trace scene`: callable on one ray (8 floats) -> FColor."""
 

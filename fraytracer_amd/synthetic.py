@@ -142,6 +142,19 @@ def console_like(seed=19, n=1000, size=1000, factory=random_torus):
     return SdfScene(obj, BACKGROUND, program_lights()), ImageSize(size, size)
 
 
+def console_scene(seed=19, n=1000, size=1000):
+    """The reference's own scene: Program.fs:14-83 with `System.Random(19)` (fraytracer_amd/dotnet_random.py,
+    re-implemented from memory — best effort, see that module), 1000 random tori, draw order of
+    Program.fs:28-30, 48-55: form fields first, then the three material draws."""
+    from .dotnet_random import Random
+    rng = Random(seed)
+    union = SdfObject.union([random_torus(rng) for _ in range(n)])
+    obj = SdfObject.subtract(
+        SdfObject.intersect(union, [SdfForm.Primitive.sphere((0.0, 0.0, 0.0), 3.5)]),
+        SdfForm.Primitive.sphere((-0.5, 1.0, -2.0), 2.5))
+    return SdfScene(obj, BACKGROUND, program_lights()), ImageSize(size, size)
+
+
 def mixed_nested(seed=7):
     """A small scene touching every combinator and primitive, including combinator children of a
     union (material resolution through nested object unions)."""

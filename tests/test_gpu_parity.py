@@ -182,3 +182,26 @@ def test_column_tiles_concatenate_to_full_frame(gpu):
         for j in range(slab.shape[0] // S):
             out[(j * R + r) * S:(j * R + r + 1) * S] = slab[j * S:(j + 1) * S]
     assert_bit_equal(out, full, "striped tiles")
+
+
+def test_render_multi_single_process_path(gpu):
+    """ft_render_multi with the one GPU this box has: stripes + (degenerate) gather + de-interleaving copy
+    must reproduce the monolithic render; two contexts on the same device exercise ft_scene_clone and the
+    thread-per-device path without a second GPU (the RCCL gather itself needs >= 2 devices)."""
+    scene, _ = syn.config2(seed=8)
+    cam = syn.default_camera()
+    W, H = 128, 72
+    full, st = gpu.scene(scene).render(EPS, LEN, ft.ImageSize(W, H), cam)
+    img, st1 = ft.render_multi([gpu], scene, EPS, LEN, ft.ImageSize(W, H), cam, stripe_width=16)
+    assert_bit_equal(img, full, "ft_render_multi n=1")
+    assert st1["rays_primary"] == st["rays_primary"] and st1["rays_shadow"] == st["rays_shadow"]
+    other = ft.Device(0)
+    try:
+        p = ft.api.C.c_void_p()
+        ft.api.check(ft.api.lib.ft_scene_clone(gpu.scene(scene)._scene, other._ctx, ft.api.C.byref(p)))
+        clone = ft.DeviceScene.__new__(ft.DeviceScene); clone.device, clone._scene = other, p
+        img2, _ = clone.render(EPS, LEN, ft.ImageSize(W, H), cam)
+        assert_bit_equal(img2, full, "cloned scene on a second context")
+        clone.close()
+    finally:
+        other.close()
