@@ -147,8 +147,8 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
     return __builtin_amdgcn_ldexpf(pz, (int)(__float_as_uint(tm) - 0x4B400000u));
 }
 
-#define FT_FAST_Q_MIN_BITS 0x0F800000u     // 2^-96
-#define FT_FAST_Q_SPAN_BITS 0x40000000u    // [2^-96, 2^32): one unsigned compare after an OR-tree
+#define FT_FAST_Q_MIN 0x1p-96f
+#define FT_FAST_P_MAX 20000.0f             // |p|inf bound under which every |c - p|^2 < 2^32 (|c|inf <= 10000, scene.cpp)
 #define FT_FAST_T_LO (-2900000.0f)         // |t * log2e| < 2^22: the magic-number rounding stays exact
 #define FT_FAST_T_HI 88.0f
 
@@ -156,11 +156,16 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 // (SdfForm.fs:77-80 with sphere children, :129).  Four children per step: their parameter reads are
 // LDS broadcasts (ds_read_b128; no SGPR operands, which halve the VALU rate on gfx950) and their four
 // dependency chains interleave.  The additions into `sum` stay in child order.
-// Guard: every |c - p|^2 of the block must lie in [2^-96, 2^32) — then ft_sqrt_fast is exact and,
-// with the flatten-time bounds on strength and radii (scene.cpp fastSphereRun), t is inside the
-// range ft_exp_fast is proved on.  NaN / inf / huge / tiny values fail the test and take the exact
-// path; (bits - 2^-96) < 2^30 for all four is tested on the OR of the four differences.
-__device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si, f3 p, float sum) {
+//
+// Preconditions, checked by the caller once per evaluation: p finite with |p|inf < FT_FAST_P_MAX.
+// With the flatten-time bounds (scene.cpp fastSphereRun: |c|inf <= 1e4, 2^-20 <= r <= 1e4, strength
+// range) every q = |c - p|^2 is finite and < 2^32, and t lies in the range ft_exp_fast is proved on.
+// Below 2^-96 (p within 1e-14 of a centre) q is clamped: sqrt(q) and sqrt(2^-96) = 2^-48 are both
+// far below half an ulp of r >= 2^-20, so d = s - r rounds to -r either way — the clamp cannot change
+// the result and ft_sqrt_fast never sees an operand outside [2^-96, 2^32).
+__device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
+    float si = si_;
+    asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
     for (; i + 4 <= count; i += 4) {
         float4 prm[4];
@@ -170,24 +175,24 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
-            q[j] = (dx * dx + dy * dy) + dz * dz;
+            q[j] = __builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN);
         }
-        const uint32_t span = ((__float_as_uint(q[0]) - FT_FAST_Q_MIN_BITS) | (__float_as_uint(q[1]) - FT_FAST_Q_MIN_BITS)) |
-                              ((__float_as_uint(q[2]) - FT_FAST_Q_MIN_BITS) | (__float_as_uint(q[3]) - FT_FAST_Q_MIN_BITS));
-        if (__builtin_expect(__ballot(span >= FT_FAST_Q_SPAN_BITS) != 0ull, 0)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum = sum + ft_exp(si * (sqrtf(q[j]) - prm[j].w));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum = sum + ft_exp_fast(si * (ft_sqrt_fast(q[j]) - prm[j].w));
-        }
+        for (int j = 0; j < 4; ++j) sum = sum + ft_exp_fast(si * (ft_sqrt_fast(q[j]) - prm[j].w));
     }
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
         const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
-        sum = sum + ft_exp(si * (sqrtf((dx * dx + dy * dy) + dz * dz) - prm.w));
+        sum = sum + ft_exp_fast(si * (ft_sqrt_fast(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)) - prm.w));
     }
     return sum;
+}
+
+// wave-uniform precondition of the fast sphere runs for this evaluation
+__device__ __forceinline__ bool fast_point_ok(f3 p) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p.x), __builtin_fabsf(p.y)), __builtin_fabsf(p.z));
+    const bool bad = !(m < FT_FAST_P_MAX) || p.x != p.x || p.y != p.y || p.z != p.z;   // fmax drops NaN operands: test them
+    return __ballot(bad) == 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -242,6 +247,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
                                         const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
     cfp consts = as_const(S.consts);
+    const bool fastOk = S.nStage != 0 && fast_point_ok(p);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
         float* dst = sd + in.dst * FT_BLOCK;
@@ -254,7 +260,7 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
             break;
         case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
             float sum = (in.flags & 1u) ? 0.0f : *dst;
-            if ((in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
+            if (fastOk && (in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
                 sum = smooth_run_spheres_fast(ldsC + in.data, in.count, in.f0, p, sum);
             } else {
                 cfp c = consts + in.data;
@@ -314,10 +320,21 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
                                                        float& outD, uint32_t& outLeaf) {
     float acc = 0.0f;
     uint32_t leaf = 0;
+    const bool fastOk = fast_point_ok(p);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr FT_CONST* in = as_const(S.instr) + pc;
         const uint32_t op = in->op;
-        if (op == FT_OP_SMOOTH_RUN) acc = smooth_run_spheres_fast(ldsC + in->data, in->count, in->f0, p, (in->flags & FT_FLAG_INIT) ? 0.0f : acc);
+        if (op == FT_OP_SMOOTH_RUN) {
+            const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
+            if (__builtin_expect(fastOk, 1)) acc = smooth_run_spheres_fast(ldsC + in->data, in->count, in->f0, p, sum0);
+            else {                                                     // exact loop (SdfForm.fs:77-80, :129)
+                acc = sum0;
+                for (uint32_t i = 0; i < in->count; ++i) {
+                    const float* c = ldsC + in->data + 4u * i;
+                    acc = acc + ft_exp(in->f0 * (ft_distance(mk3(c[0], c[1], c[2]), p) - c[3]));
+                }
+            }
+        }
         else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log(acc) * in->f0;
         else leaf = in->aux;                                           // FT_OP_SETLEAF
     }

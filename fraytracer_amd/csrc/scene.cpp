@@ -317,13 +317,15 @@ struct Flattener {
         if (b.forms[f.kids[k]].kind != HostForm::SPHERE) return false;
         if (!(f.strength > 0.0f) || !std::isfinite(strengthInverse)) return false;
         const float a = fabsf(strengthInverse);
-        // the kernel guards |c - p| < 65536, so |t| <= a * (65536 + r) must stay below 2.9e6 (a <= 32,
-        // r <= 1e4) and t <= a * r must stay below 88 (a * r <= 80); r >= 0 keeps t <= a * r.
+        // the kernel checks |p|inf < 20000 per evaluation; with |c|inf <= 1e4 that gives |c - p| < 65536, so
+        // |t| <= a * (65536 + r) stays below 2.9e6 (a <= 32, r <= 1e4) and t <= a * r below 88 (a * r <= 80).
+        // r >= 2^-20 makes the kernel's clamp of tiny |c - p|^2 result-neutral.
         if (!(a <= 32.0f) || !(a >= 0x1p-20f)) return false;
         for (size_t j = 0; j < run; ++j) {
             const std::vector<float>& p = b.forms[f.kids[k + j]].params;
             for (int c = 0; c < 4; ++c) if (!std::isfinite(p[c])) return false;
-            if (!(p[3] >= 0.0f) || !(p[3] <= 1.0e4f) || !(p[3] * a <= 80.0f)) return false;
+            for (int c = 0; c < 3; ++c) if (!(fabsf(p[c]) <= 1.0e4f)) return false;
+            if (!(p[3] >= 0x1p-20f) || !(p[3] <= 1.0e4f) || !(p[3] * a <= 80.0f)) return false;
         }
         return true;
     }

@@ -18,6 +18,8 @@ cam = syn.default_camera()
 cases = [("C1 sphere 256^2", syn.config1()[0], 256), ("C2 union32 1024^2", syn.config2()[0], 1024),
          ("C2 union32+boxes 1024^2", syn.config2(boxes=True)[0], 1024),
          ("console-like 1000 tori 1000^2", syn.console_like(n=1000)[0], 1000),
+         ("console-like 1000 tori 4000^2", syn.console_like(n=1000)[0], 4000),
+         ("C2 union32 4096^2", syn.config2()[0], 4096),
          ("mixed nested 1024^2", syn.mixed_nested()[0], 1024),
          ("C3 smooth256 4096^2", syn.config3()[0], 4096), ("C4 smooth256 8192^2", syn.config3()[0], 8192)]
 only = sys.argv[1:] 
