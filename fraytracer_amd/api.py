@@ -340,14 +340,16 @@ class DeviceScene:
         return {"aabbMin": np.array(info[0:3], np.float32), "cellSizeInv": np.array(info[3:6], np.float32),
                 "counts": tuple(counts), "cell_start": cell_start, "centers": centers, "lower": lower, "child": child}
 
-    def _params(self, imageSize, epsilon, length, x0=0, n_columns=None, stripe_width=None, stripe_ranks=1, stripe_rank=0):
+    def _params(self, imageSize, epsilon, length, x0=0, n_columns=None, stripe_width=None, stripe_ranks=1, stripe_rank=0,
+                spp=1, ao_samples=0, ao_radius=0.0):
+        """spp / ao_samples / ao_radius are EXTENSIONS (not in the reference); defaults = the reference."""
         W, H = int(imageSize.X), int(imageSize.Y)
         if n_columns is None:
             n_columns = W - x0 if stripe_ranks == 1 else W // stripe_ranks
         if stripe_width is None:
             stripe_width = n_columns
         return _lib.RenderParams(W, H, int(x0), int(n_columns), int(stripe_width), int(stripe_ranks), int(stripe_rank),
-                                 1, float(epsilon), float(length), 0, 0.0)
+                                 int(spp), float(epsilon), float(length), int(ao_samples), float(ao_radius))
 
     def render(self, epsilon, length, imageSize, camera, **tiling):
         """Image.render (Image.fs:26-35) -> (FColor[X,Y] as float32 [n_columns, Y, 3], stats dict)."""

@@ -36,6 +36,7 @@ struct ft_ctx {
     uint32_t* dCounter = nullptr;
     FtStatsDev* dStats = nullptr;
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
+    void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
 };
@@ -125,7 +126,7 @@ int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
 // launch the persistent trace kernel over nJobs jobs
 int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     int perCU = 0;
-    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, ldsBytes(s), &perCU));
+    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.spp != 1u || a.aoSamples != 0u, ldsBytes(s), &perCU));
     perCU = std::max(1, std::min(perCU, 8));
     if (const char* e = getenv("FT_BLOCKS_PER_CU")) perCU = std::max(1, std::min(perCU, atoi(e)));   // tuning experiments only
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
@@ -156,13 +157,15 @@ int checkParams(const ft_render_params* p) {
     if (p->width <= 0 || p->height <= 0 || p->n_columns <= 0) return setErr(FT_ERR_INVALID, "empty image");
     if (p->stripe_width <= 0 || p->stripe_ranks <= 0 || p->stripe_rank < 0 || p->stripe_rank >= p->stripe_ranks)
         return setErr(FT_ERR_INVALID, "bad stripe description");
-    if (p->spp != 1 || p->ao_samples != 0) return setErr(FT_ERR_UNSUPPORTED, "spp > 1 / ambient occlusion are extensions not built yet");
+    int sn = 1; while (sn * sn < p->spp) ++sn;
+    if (p->spp < 1 || p->spp > 64 || sn * sn != p->spp) return setErr(FT_ERR_INVALID, "spp (extension) must be a square number <= 64");
+    if (p->ao_samples < 0 || p->ao_samples > 16) return setErr(FT_ERR_INVALID, "ao_samples (extension) must be in [0, 16]");
     // last local column must map inside the image
     const int64_t c = (int64_t)p->n_columns - 1;
     const int64_t x = p->x0 + (c / p->stripe_width) * (int64_t)p->stripe_width * p->stripe_ranks + (int64_t)p->stripe_rank * p->stripe_width + c % p->stripe_width;
     if (p->x0 < 0 || x >= p->width) return setErr(FT_ERR_INVALID, "column range leaves the image");
     const uint64_t tiles = (uint64_t)((p->n_columns + 7) / 8) * (uint64_t)((p->height + 7) / 8);
-    if (tiles * 64 >= 0xFFFF0000ull) return setErr(FT_ERR_UNSUPPORTED, "more than 2^32 pixels in one call");
+    if (tiles * 64 * (uint64_t)p->spp >= 0xFFFF0000ull) return setErr(FT_ERR_UNSUPPORTED, "more than 2^32 samples in one call");
     return FT_OK;
 }
 
@@ -206,6 +209,7 @@ void ft_ctx_destroy(ft_ctx* c) {
         for (auto& p : c->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto& p : c->eventPool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (c->scratch) (void)hipFree(c->scratch);
+        if (c->planes) (void)hipFree(c->planes);
         if (c->dCounter) (void)hipFree(c->dCounter);
         if (c->dStats) (void)hipFree(c->dStats);
         if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -333,10 +337,25 @@ int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const f
     a.mode = 0;
     a.maxSize = (float)std::max(p->width, p->height);              // Image.fs:18
     a.eps = p->epsilon; a.length = p->length;
-    a.out = static_cast<float*>(d_out);
     a.tilesY = (uint32_t)((p->height + 7) / 8);
-    a.nJobs = (uint32_t)((p->n_columns + 7) / 8) * a.tilesY * 64u;
-    return launchTrace(c, s, a);
+    a.jobsPerPlane = (uint32_t)((p->n_columns + 7) / 8) * a.tilesY * 64u;
+    a.spp = (uint32_t)p->spp; a.sppN = 1; while (a.sppN * a.sppN < a.spp) ++a.sppN;
+    a.aoSamples = (uint32_t)p->ao_samples; a.aoRadius = p->ao_radius;
+    a.planePixels = (uint32_t)p->n_columns * (uint32_t)p->height;
+    a.nJobs = a.jobsPerPlane * a.spp;
+    if (a.spp == 1) { a.out = static_cast<float*>(d_out); return launchTrace(c, s, a); }
+    // EXTENSION: one frame per sample, then a fixed-order resolve
+    const size_t planeFloats = (size_t)a.planePixels * 3;
+    const size_t need = planeFloats * a.spp * sizeof(float);
+    if (need > c->planesBytes) {
+        if (c->planes) { HIP_TRY(hipFree(c->planes)); c->planes = nullptr; c->planesBytes = 0; }
+        HIP_TRY(hipMalloc(&c->planes, need));
+        c->planesBytes = need;
+    }
+    a.out = static_cast<float*>(c->planes);
+    if ((rc = launchTrace(c, s, a))) return rc;
+    HIP_TRY(ft_launch_resolve(static_cast<const float*>(c->planes), static_cast<float*>(d_out), planeFloats, a.spp, c->stream));
+    return FT_OK;
 }
 
 int ft_collect_stats(ft_ctx* c, ft_stats* st) {
@@ -384,6 +403,7 @@ int ft_trace_rays(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, f
     FtRenderArgs a{};
     a.mode = 1; a.rays = reinterpret_cast<const ft_ray*>(base); a.out = reinterpret_cast<float*>(base + rayBytes);
     a.nJobs = (uint32_t)n; a.stripeW = 1; a.stripeRanks = 1; a.tilesY = 1; a.H = 1; a.W = 1; a.nCols = 1; a.maxSize = 1.0f;
+    a.spp = 1; a.sppN = 1; a.jobsPerPlane = a.nJobs; a.planePixels = a.nJobs;
     if ((rc = launchTrace(c, s, a))) return rc;
     HIP_TRY(hipMemcpyAsync(out, base + rayBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
     return ft_collect_stats(c, st);

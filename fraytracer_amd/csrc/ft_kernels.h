@@ -19,6 +19,10 @@ struct FtRenderArgs {
     uint32_t* counter;        // global job cursor (zeroed before every launch)
     FtStatsDev* stats;
     uint32_t nJobs, chunk, tilesY, pad1;
+    // EXTENSIONS (spp = 1, aoSamples = 0 is the reference): sample plane s of the frame is written at
+    // out + s * planeFloats and resolved by ft_resolve_kernel; ambient-occlusion rays per primary hit
+    uint32_t spp, sppN, aoSamples, jobsPerPlane;
+    float aoRadius; uint32_t planePixels, pad2, pad3;
 };
 
 #ifdef __cplusplus
@@ -28,8 +32,9 @@ hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsByt
 hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
                                  unsigned blocks, size_t ldsBytes, hipStream_t st);
 hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st);
+hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
-hipError_t ft_trace_occupancy(unsigned fastPath, size_t ldsBytes, int* blocksPerCU);
+hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus
 }
 #endif

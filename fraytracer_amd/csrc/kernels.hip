@@ -344,7 +344,20 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
 // ------------------------------------------------------------------------------------------------
 // render / trace kernel
 // ------------------------------------------------------------------------------------------------
-enum : uint32_t { PH_IDLE = 0, PH_DONE, PH_MARCH, PH_NX, PH_NY, PH_NZ, PH_NC, PH_LIGHTS, PH_SHADOW };
+// phases >= PH_MARCH need one scene-SDF evaluation per round
+enum : uint32_t { PH_IDLE = 0, PH_DONE, PH_LIGHTS, PH_AONEXT, PH_MARCH, PH_NX, PH_NY, PH_NZ, PH_NC, PH_SHADOW, PH_AO };
+
+// EXTENSION: fixed ambient-occlusion directions (16 Fibonacci-sphere points); the ray k leaves the hit
+// point along normalize(Normal + FT_AO_DIRS[k]).  Same table as the oracle's AO_DIRS.
+__constant__ float FT_AO_DIRS[16][3] = {
+    {0x1.02414ep-3f, -0x1.4c1e18p-2f, 0x1.e00000p-1f}, {-0x1.0bab14p-1f, 0x1.082252p-2f, 0x1.a00000p-1f},
+    {0x1.64fce8p-1f, 0x1.9faf66p-3f, 0x1.600000p-1f}, {-0x1.b78ec2p-2f, -0x1.69cc1ap-1f, 0x1.200000p-1f},
+    {-0x1.662d3ep-3f, 0x1.c39baap-1f, 0x1.c00000p-2f}, {0x1.88019ap-1f, -0x1.1fe15ep-1f, 0x1.400000p-2f},
+    {-0x1.f3fa74p-1f, -0x1.b27cbep-4f, 0x1.800000p-3f}, {0x1.5150bap-1f, 0x1.7fd8c8p-1f, 0x1.000000p-4f},
+    {0x1.51e2d4p-6f, -0x1.fee3d2p-1f, -0x1.000000p-4f}, {-0x1.5b4eb4p-1f, 0x1.6bbd02p-1f, -0x1.800000p-3f},
+    {0x1.e54554p-1f, -0x1.03ffa2p-4f, -0x1.400000p-2f}, {-0x1.6781e0p-1f, -0x1.1f9d7cp-1f, -0x1.c00000p-2f},
+    {0x1.046c0ap-3f, 0x1.a248a2p-1f, -0x1.200000p-1f}, {0x1.9bff54p-2f, -0x1.3585eap-1f, -0x1.600000p-1f},
+    {-0x1.21c850p-1f, 0x1.1e0d66p-3f, -0x1.a00000p-1f}, {0x1.38c4f8p-2f, 0x1.55799ap-3f, -0x1.e00000p-1f}};
 
 struct LaneState {
     uint32_t phase, job, steps, lidx, leaf, outIdx;
@@ -355,7 +368,8 @@ struct LaneState {
     f3 lacc;              // lightColor (SdfScene.fs:12)
     f3 lint;              // intensity the current light adds when unshadowed
     float lcos;
-    uint32_t cEvals, cShadow, cHitP, cHitS, cPrimary, cFlags;
+    uint32_t aoIdx, aoOpen;   // EXTENSION: ambient-occlusion ray counter / unoccluded count
+    uint32_t cEvals, cShadow, cHitP, cHitS, cPrimary, cFlags, cExt;
 };
 
 __device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx, f3 c) {
@@ -365,6 +379,7 @@ __device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx,
 
 // advance a lane until it needs an SDF evaluation (or is idle): everything in SdfScene.trace that
 // is not a Distance call.
+template <bool EXT>
 __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
     const float piInv = 1.0f / 3.14159274101257324f;                   // Math.fs:28-30
     for (;;) {
@@ -374,6 +389,24 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
                 s.phase = PH_IDLE;
             }
             return;
+        }
+        if (EXT && s.phase == PH_AO) {                                 // EXTENSION
+            if (s.len <= 0.0f) { s.aoOpen += 1; s.aoIdx += 1; s.phase = PH_AONEXT; continue; }
+            return;
+        }
+        if (EXT && s.phase == PH_AONEXT) {                             // EXTENSION
+            if (s.aoIdx >= a.aoSamples) {
+                const float f = (float)s.aoOpen / (float)a.aoSamples;
+                s.lacc = mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]) * f;
+                s.lidx = 0; s.phase = PH_LIGHTS;
+                continue;
+            }
+            const f3 dir = ft_normalize(s.nrm + mk3(FT_AO_DIRS[s.aoIdx][0], FT_AO_DIRS[s.aoIdx][1], FT_AO_DIRS[s.aoIdx][2]));
+            s.cExt += 1;
+            if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.aoOpen += 1; s.aoIdx += 1; continue; }
+            s.o = s.hp; s.dir = dir; s.len = a.aoRadius; s.steps = 0;
+            s.phase = PH_AO;
+            continue;
         }
         if (s.phase == PH_SHADOW) {
             if (s.len <= 0.0f) {                                       // shadow ray missed: light arrives
@@ -421,6 +454,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
     }
 }
 
+template <bool EXT>
 __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
     if (a.mode == 1) {                                                 // explicit ray buffer (SdfScene.trace scene ray)
         const ft_ray r = a.rays[s.job];
@@ -429,21 +463,25 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
         s.len = r.length; s.eps = r.epsilon;
         s.outIdx = s.job;
     } else {                                                           // Image.render (Image.fs:28-34)
-        const uint32_t t = s.job >> 6, i = s.job & 63u;
+        const uint32_t smp = EXT ? s.job / a.jobsPerPlane : 0u, jp = s.job - smp * a.jobsPerPlane;   // EXTENSION: sample plane (0 for spp = 1)
+        const uint32_t t = jp >> 6, i = jp & 63u;
         const uint32_t tx = t / a.tilesY, ty = t - tx * a.tilesY;
         const uint32_t cl = tx * 8u + (i >> 3), y = ty * 8u + (i & 7u);
         if (cl >= (uint32_t)a.nCols || y >= (uint32_t)a.H) { s.phase = PH_IDLE; return; }
         const uint32_t x = (uint32_t)a.x0 + (cl / a.stripeW) * (a.stripeW * a.stripeRanks) + a.stripeRank * a.stripeW + cl % a.stripeW;
-        const float px = (float)x / a.maxSize, py = (float)y / a.maxSize;     // Image.fs:20-23
+        // Image.fs:20-23: position = x / max(W,H); sample offsets (smp % n)/n, (smp / n)/n are 0 for spp = 1
+        const float ox = EXT ? (float)(smp % a.sppN) / (float)a.sppN : 0.0f, oy = EXT ? (float)(smp / a.sppN) / (float)a.sppN : 0.0f;
+        const float px = EXT ? ((float)x + ox) / a.maxSize : (float)x / a.maxSize;
+        const float py = EXT ? ((float)y + oy) / a.maxSize : (float)y / a.maxSize;
         const f3 fw = mk3(a.cam[3], a.cam[4], a.cam[5]), up = mk3(a.cam[6], a.cam[7], a.cam[8]), rt = mk3(a.cam[9], a.cam[10], a.cam[11]);
         s.o = mk3(a.cam[0], a.cam[1], a.cam[2]);
         s.dir = ft_normalize(fw + (px - 0.5f) * rt + (py - 0.5f) * up);       // Camera.fs:48-51
         s.len = a.length; s.eps = a.eps;
-        s.outIdx = cl * (uint32_t)a.H + y;
+        s.outIdx = smp * a.planePixels + cl * (uint32_t)a.H + y;
     }
     s.steps = 0; s.cPrimary += 1;
     s.phase = PH_MARCH;
-    settle(a, s);
+    settle<EXT>(a, s);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
@@ -454,7 +492,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 
 extern __shared__ float ft_lds[];
 
-template <int VARIANT>
+template <int VARIANT, bool EXT>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     float* sd = ft_lds + tid;
@@ -470,7 +508,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
     s.o = s.dir = s.hp = s.nrm = s.lacc = s.lint = mk3(0, 0, 0);
     s.len = 0; s.eps = 0; s.lcos = 0;
-    s.cEvals = s.cShadow = s.cHitP = s.cHitS = s.cPrimary = s.cFlags = 0;
+    s.cEvals = s.cShadow = s.cHitP = s.cHitS = s.cPrimary = s.cFlags = s.cExt = 0;
+    s.aoIdx = s.aoOpen = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk ------------------------------------------
@@ -489,14 +528,14 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             const uint32_t avail = chunkEnd - chunkNext;
             const uint32_t nIdle = (uint32_t)__popcll(idle);
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (s.phase == PH_IDLE && rank < avail) { s.job = chunkNext + rank; start_job(a, s); }
+            if (s.phase == PH_IDLE && rank < avail) { s.job = chunkNext + rank; start_job<EXT>(a, s); }
             chunkNext += (nIdle < avail) ? nIdle : avail;
         }
         if (s.phase == PH_IDLE && exhausted && chunkNext == chunkEnd) s.phase = PH_DONE;
         if (__ballot(s.phase != PH_DONE) == 0ull) break;
 
         // ---- one scene-SDF evaluation per active lane -----------------------------------------
-        const bool active = s.phase >= PH_MARCH && s.phase != PH_LIGHTS;
+        const bool active = s.phase >= PH_MARCH;
         waveEvals += 1;
         if (active) {
             f3 q = s.o;
@@ -515,13 +554,14 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
 
             switch (s.phase) {
             case PH_MARCH:
-            case PH_SHADOW: {
-                const bool primary = s.phase == PH_MARCH;
+            case PH_SHADOW:
+            case PH_AO: {
                 bool miss = false;
                 if (d != d) { s.cFlags |= 1u; miss = true; }           // reference would never terminate
                 else if (d < s.eps) {                                  // SdfForm.fs:98
-                    if (primary) { s.cHitP += 1; s.leaf = leaf; s.phase = PH_NX; }
-                    else { s.cHitS += 1; s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
+                    if (s.phase == PH_MARCH) { s.cHitP += 1; s.leaf = leaf; s.phase = PH_NX; }
+                    else if (s.phase == PH_SHADOW) { s.cHitS += 1; s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
+                    else { s.aoIdx += 1; s.phase = PH_AONEXT; }        // EXTENSION: occluded
                 } else {
                     s.o = s.o + s.dir * d;                             // Ray.move (Ray.fs:9-13)
                     s.len = s.len - d;
@@ -540,17 +580,18 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 s.lacc = mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]);         // SdfScene.fs:12
                 s.lidx = 0;
                 s.phase = PH_LIGHTS;
+                if (EXT && a.aoSamples != 0u) { s.aoIdx = 0; s.aoOpen = 0; s.phase = PH_AONEXT; }   // EXTENSION
                 break;
             }
             default: break;
             }
-            settle(a, s);
+            settle<EXT>(a, s);
         }
     }
 
     // ---- statistics -------------------------------------------------------------------------
     const unsigned long long e = wave_sum(s.cEvals), sh = wave_sum(s.cShadow), hp = wave_sum(s.cHitP),
-                             hs = wave_sum(s.cHitS), pr = wave_sum(s.cPrimary);
+                             hs = wave_sum(s.cHitS), pr = wave_sum(s.cPrimary), ex = wave_sum(s.cExt);
     const unsigned long long fl = __ballot((s.cFlags & 1u) != 0) ? 1ull : 0ull;
     const unsigned long long fc = __ballot((s.cFlags & 4u) != 0) ? 4ull : 0ull;
     if (lane == 0) {
@@ -559,15 +600,19 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         atomicAdd(&a.stats->hits_primary, hp);
         atomicAdd(&a.stats->hits_shadow, hs);
         atomicAdd(&a.stats->rays_primary, pr);
+        if (ex) atomicAdd(&a.stats->rays_ext, ex);
         atomicAdd(&a.stats->wave_evals, (unsigned long long)waveEvals);
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
     }
 }
 
 // general scenes
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtRenderArgs a) { ft_trace_body<0>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtRenderArgs a) { ft_trace_body<0, false>(a); }
 // scenes that are one smooth union of spheres (BASELINE.json config 3/4)
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres(const FtRenderArgs a) { ft_trace_body<1>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres(const FtRenderArgs a) { ft_trace_body<1, false>(a); }
+// EXTENSION builds of both (spp > 1 and / or ambient occlusion); the reference path never pays for them
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_ext(const FtRenderArgs a) { ft_trace_body<0, true>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_ext(const FtRenderArgs a) { ft_trace_body<1, true>(a); }
 
 // scene.Object.Form.Distance at explicit points (test / diagnostic entry)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
@@ -603,6 +648,15 @@ extern "C" __global__ void ft_math_kernel(int op, const float* __restrict__ x, c
     }
 }
 
+// EXTENSION (spp > 1): pixel = (sample 0 + sample 1 + ... in order) / spp, per float, fixed order
+extern "C" __global__ void ft_resolve_kernel(const float* __restrict__ planes, float* __restrict__ out, unsigned long long nFloats, unsigned spp) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nFloats; i += (unsigned long long)gridDim.x * blockDim.x) {
+        float c = planes[i];
+        for (unsigned k = 1; k < spp; ++k) c = c + planes[(unsigned long long)k * nFloats + i];
+        out[i] = c / (float)spp;
+    }
+}
+
 // exhaustive proof of the fast forms: every float bit pattern in [lo, hi] (same sign), fast vs exact
 extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, unsigned long long* mismatches) {
     unsigned long long bad = 0;
@@ -620,7 +674,10 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
 // host-callable launchers (kept in this translation unit so the C ABI file is plain C++)
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
-    if (a->S.fastPath == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    const bool ext = a->spp != 1u || a->aoSamples != 0u;
+    if (a->S.fastPath == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    else if (ext) hipLaunchKernelGGL(ft_trace_kernel_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    else if (a->S.fastPath == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     return hipGetLastError();
 }
@@ -633,11 +690,16 @@ extern "C" hipError_t ft_launch_math(int op, const float* x, const float* y, lon
     hipLaunchKernelGGL(ft_math_kernel, dim3(1024), dim3(256), 0, st, op, x, y, n, out);
     return hipGetLastError();
 }
+extern "C" hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st) {
+    hipLaunchKernelGGL(ft_resolve_kernel, dim3(2048), dim3(256), 0, st, planes, out, nFloats, spp);
+    return hipGetLastError();
+}
 extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st) {
     hipLaunchKernelGGL(ft_selftest_kernel, dim3(4096), dim3(256), 0, st, op, lo, hi, d_mismatches);
     return hipGetLastError();
 }
-extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, size_t ldsBytes, int* blocksPerCU) {
+extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU) {
+    if (ext) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, fastPath == 1 ? ft_trace_kernel_smooth_spheres_ext : ft_trace_kernel_ext, FT_BLOCK, ldsBytes);
     if (fastPath == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel_smooth_spheres, FT_BLOCK, ldsBytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel, FT_BLOCK, ldsBytes);
 }

@@ -60,6 +60,7 @@ def _load():
         "orc_trace_rays": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Counters)]),
         "orc_render": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
         "orc_render_strided": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
+        "orc_render_ext": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
         "orc_pixel_ray": (None, [f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f3]),
     }
     for name, (res, args) in sig.items():
@@ -156,14 +157,15 @@ class OracleScene:
         self.handle = handle
         self.object = obj
 
-    def render(self, epsilon, length, W, H, cam12, x0=0, x1=None, nthreads=None, xstep=1):
+    def render(self, epsilon, length, W, H, cam12, x0=0, x1=None, nthreads=None, xstep=1, spp=1, ao_samples=0, ao_radius=0.0):
         x1 = W if x1 is None else x1
         nthreads = nthreads or min(32, os.cpu_count() or 1)
         ncols = (x1 - x0 + xstep - 1) // xstep
         out = np.empty((ncols, H, 3), np.float32)
         cnt = Counters()
         cam = (C.c_float * 12)(*[float(v) for v in cam12])
-        _ck(lib.orc_render_strided(self.handle, cam, W, H, x0, x1, xstep, epsilon, length, out.ctypes.data_as(C.c_void_p), nthreads, C.byref(cnt)))
+        _ck(lib.orc_render_ext(self.handle, cam, W, H, x0, x1, xstep, epsilon, length, spp, ao_samples, ao_radius,
+                               out.ctypes.data_as(C.c_void_p), nthreads, C.byref(cnt)))
         return out, cnt.as_dict()
 
     def trace_rays(self, rays):

@@ -652,6 +652,54 @@ FColor Scene_trace(const SdfScene& scene, const Ray& ray) {                  // 
 }
 
 // ---------------------------------------------------------------------------
+// EXTENSIONS (not in the reference; BASELINE.json configs ask for them): ambient occlusion and
+// several samples per pixel.  Defined here only so that the product's extension has a checker;
+// no parity claim is attached to them.
+//   AO: after a primary hit, `aoSamples` rays (<= 16) leave the pulled-back hit point in the directions
+//   normalize(Normal + AO_DIRS[k]) with Length = aoRadius and the ray's Epsilon, marched with
+//   SdfForm.tryTrace; lightColor starts as BackgroundColor * (unoccluded / aoSamples) instead of
+//   BackgroundColor.  A NaN direction (zero gradient) counts as unoccluded without a march.
+//   spp = n*n: sample k uses the pixel corner offset ((k % n) / n, (k / n) / n); the pixel is the sum
+//   of the samples in order divided by spp.  spp = 1, aoSamples = 0 is exactly the reference.
+// ---------------------------------------------------------------------------
+const float AO_DIRS[16][3] = {
+    {0x1.02414ep-3f, -0x1.4c1e18p-2f, 0x1.e00000p-1f}, {-0x1.0bab14p-1f, 0x1.082252p-2f, 0x1.a00000p-1f},
+    {0x1.64fce8p-1f, 0x1.9faf66p-3f, 0x1.600000p-1f}, {-0x1.b78ec2p-2f, -0x1.69cc1ap-1f, 0x1.200000p-1f},
+    {-0x1.662d3ep-3f, 0x1.c39baap-1f, 0x1.c00000p-2f}, {0x1.88019ap-1f, -0x1.1fe15ep-1f, 0x1.400000p-2f},
+    {-0x1.f3fa74p-1f, -0x1.b27cbep-4f, 0x1.800000p-3f}, {0x1.5150bap-1f, 0x1.7fd8c8p-1f, 0x1.000000p-4f},
+    {0x1.51e2d4p-6f, -0x1.fee3d2p-1f, -0x1.000000p-4f}, {-0x1.5b4eb4p-1f, 0x1.6bbd02p-1f, -0x1.800000p-3f},
+    {0x1.e54554p-1f, -0x1.03ffa2p-4f, -0x1.400000p-2f}, {-0x1.6781e0p-1f, -0x1.1f9d7cp-1f, -0x1.c00000p-2f},
+    {0x1.046c0ap-3f, 0x1.a248a2p-1f, -0x1.200000p-1f}, {0x1.9bff54p-2f, -0x1.3585eap-1f, -0x1.600000p-1f},
+    {-0x1.21c850p-1f, 0x1.1e0d66p-3f, -0x1.a00000p-1f}, {0x1.38c4f8p-2f, 0x1.55799ap-3f, -0x1.e00000p-1f}};
+
+FColor Scene_trace_ext(const SdfScene& scene, const Ray& ray, int aoSamples, float aoRadius) {
+    if (aoSamples <= 0) return Scene_trace(scene, ray);
+    SdfObjectTraceResult result;
+    tl_cnt.rays_primary++;
+    if (!Object_tryTrace(scene.Object, ray, result)) return scene.BackgroundColor;
+    tl_cnt.hits_primary++;
+    int open = 0;
+    for (int k = 0; k < aoSamples; ++k) {
+        V3 dir = Normalize(result.Normal + v3(AO_DIRS[k][0], AO_DIRS[k][1], AO_DIRS[k][2]));
+        tl_cnt.rays_ext++;
+        if (dir.X != dir.X || dir.Y != dir.Y || dir.Z != dir.Z) { open++; continue; }
+        Ray r{result.ray.Origin, dir, aoRadius, ray.Epsilon};
+        SdfFormTraceResult tr;
+        if (!Form_tryTrace(scene.Object.Form, r, tr)) open++;
+    }
+    FColor lightColor = scene.BackgroundColor * ((float)open / (float)aoSamples);
+    for (const SdfLight& light : scene.Lights) {                             // SdfScene.fs:13-26 unchanged
+        V3 lightDirection = light.Direction(result.ray.Origin);
+        float lightCos = Dot(result.Normal, lightDirection);
+        if (lightCos > 0.0f) {
+            FColor intensity;
+            if (light.Intensity(scene.Object, result.ray, intensity)) lightColor = lightColor + intensity * lightCos;
+        }
+    }
+    return result.Color * (lightColor * piInv);
+}
+
+// ---------------------------------------------------------------------------
 // Camera.fs:11-54, Image.fs:17-35
 // ---------------------------------------------------------------------------
 struct Camera { V3 Position, Forward, UpScaled, RightScaled; };              // Camera.fs:16-22
@@ -872,9 +920,20 @@ int orc_trace_rays(int scene, const float* rays, int64_t n, float* out, orc_coun
 // Image.render (Image.fs:26-35) over columns [x0, x1) of a W x H image; out is
 // (x1-x0) x H x 3 floats, x-major / y contiguous like FColor[X,Y] (Array2D.fs:30-38).
 // Threading mirrors Array2D.fs:32: workers pull whole x-columns.
+int orc_render_ext(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
+               float epsilon, float length, int spp, int aoSamples, float aoRadius, float* out, int nthreads, orc_counters* cnt);
+
 // `xstep` > 1 renders only columns x0, x0+xstep, ... (< x1): the bounded sample bench.py times.
 int orc_render_strided(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
                float epsilon, float length, float* out, int nthreads, orc_counters* cnt) {
+    return orc_render_ext(scene, cam, W, H, x0, x1, xstep, epsilon, length, 1, 0, 0.0f, out, nthreads, cnt);
+}
+
+// spp / aoSamples: EXTENSIONS (see Scene_trace_ext); spp = 1, aoSamples = 0 is the reference's Image.render
+int orc_render_ext(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
+               float epsilon, float length, int spp, int aoSamples, float aoRadius, float* out, int nthreads, orc_counters* cnt) {
+    int sn = 1; while (sn * sn < spp) ++sn;
+    if (spp < 1 || sn * sn != spp || aoSamples < 0 || aoSamples > 16) return fail("spp must be a square, ao_samples <= 16");
     if (scene < 0 || (size_t)scene >= g_scenes.size()) return fail("bad scene handle");
     if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1 || xstep < 1) return fail("bad image range");
     const SdfScene& sc = g_scenes[scene];
@@ -890,9 +949,20 @@ int orc_render_strided(int scene, const float cam[12], int W, int H, int x0, int
             const int x = x0 + col * xstep;
             if (x >= x1) break;
             for (int y = 0; y < H; ++y) {                                    // Array2D.fs:33
-                V2 pos{(float)x / maxSize, (float)y / maxSize};              // Image.fs:20-23,30
-                Ray ray = Camera_uniformPixelToRay(epsilon, length, camera, pos);  // Image.fs:32
-                FColor c = Scene_trace(sc, ray);                             // Image.fs:34
+                FColor c{v3s(0.0f)};
+                if (spp == 1 && aoSamples == 0) {
+                    V2 pos{(float)x / maxSize, (float)y / maxSize};          // Image.fs:20-23,30
+                    Ray ray = Camera_uniformPixelToRay(epsilon, length, camera, pos);  // Image.fs:32
+                    c = Scene_trace(sc, ray);                                // Image.fs:34
+                } else {                                                     // EXTENSION
+                    for (int k = 0; k < spp; ++k) {
+                        V2 pos{((float)x + (float)(k % sn) / (float)sn) / maxSize, ((float)y + (float)(k / sn) / (float)sn) / maxSize};
+                        Ray ray = Camera_uniformPixelToRay(epsilon, length, camera, pos);
+                        FColor sc_ = Scene_trace_ext(sc, ray, aoSamples, aoRadius);
+                        c = k == 0 ? sc_ : c + sc_;
+                    }
+                    if (spp > 1) c = c / (float)spp;
+                }
                 float* o = out + ((size_t)col * H + y) * 3;
                 o[0] = c.c.X; o[1] = c.c.Y; o[2] = c.c.Z;
             }

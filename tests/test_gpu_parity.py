@@ -205,3 +205,28 @@ def test_render_multi_single_process_path(gpu):
         clone.close()
     finally:
         other.close()
+
+
+# ---- EXTENSIONS (no reference counterpart; checked against the oracle's own definition only) ------------
+@pytest.mark.parametrize("spp,ao", [(4, 0), (1, 8), (4, 16), (9, 3)])
+def test_extension_spp_and_ambient_occlusion(gpu, oracle, spp, ao):
+    cam = syn.default_camera()
+    for scene, n in ((syn.config2(boxes=True)[0], 96), (syn.config3(n=48)[0], 64)):
+        ds, os_ = both(gpu, oracle, scene)
+        g, gst = ds.render(EPS, LEN, ft.ImageSize(n, n), cam, spp=spp, ao_samples=ao, ao_radius=0.75)
+        o, ocnt = os_.render(EPS, LEN, n, n, cam.as_array(), spp=spp, ao_samples=ao, ao_radius=0.75)
+        assert_bit_equal(g, o, f"extension spp={spp} ao={ao}")
+        assert gst["rays_primary"] == ocnt["rays_primary"] == n * n * spp
+        assert gst["rays_ext"] == ocnt["rays_ext"] and (ao == 0 or gst["rays_ext"] > 0)
+        assert gst["rays_shadow"] == ocnt["rays_shadow"]
+
+
+def test_extension_defaults_are_the_reference_path(gpu):
+    scene, _ = syn.config2(seed=12)
+    cam = syn.default_camera()
+    ds = gpu.scene(scene)
+    a, _ = ds.render(EPS, LEN, ft.ImageSize(80, 80), cam)
+    b, _ = ds.render(EPS, LEN, ft.ImageSize(80, 80), cam, spp=1, ao_samples=0, ao_radius=3.0)
+    assert_bit_equal(a, b, "spp=1, ao=0")
+    with pytest.raises(ft.FrayTracerError):
+        ds.render(EPS, LEN, ft.ImageSize(8, 8), cam, spp=3)
