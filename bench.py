@@ -40,6 +40,21 @@ def algorithmic_flops(stats, n_children, flops_per_child=13, flops_per_eval=3):
     return evals * (n_children * flops_per_child + flops_per_eval) + 8 * steps + 20 * normals + 25 * stats["rays_shadow"]
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, tools/profile.sh).  FETCH_SIZE is doubled as the
+    MI355X guide prescribes for gfx950; both counters are in KiB.  None if no profile is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.txt")))
+    for f in reversed(files):
+        txt = open(f).read()
+        fe, wr = re.search(r"FETCH_SIZE\s+([0-9.e+]+)", txt), re.search(r"WRITE_SIZE\s+([0-9.e+]+)", txt)
+        if fe and wr and "smooth_spheres" in txt:
+            return int((2.0 * float(fe.group(1)) + float(wr.group(1))) * 1024), os.path.basename(f)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +141,7 @@ def main():
         mrays = rays / dt / 1e6
         # roofline of the dominant (only) kernel, from this rank's launches: algorithmic lane-ops per
         # launch / mean HIP-event duration of a launch
+        traffic, traffic_src = pmc_traffic_bytes() if (W == 4096 and world == 1) else (None, None)
         flops_launch = algorithmic_flops(st, args.spheres) / args.steps
         launch_s = st["kernel_ms"] / 1e3 / args.steps
         achieved = flops_launch / launch_s / 1e12
@@ -142,11 +158,12 @@ def main():
                        "nan_or_cap_flags": flags,
                        "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": None,
-                         "kernel": "ft_trace_kernel", "kernel_ms": round(launch_s * 1e3, 3),
+                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "ft_trace_kernel_smooth_spheres", "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
-                         "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity). HBM traffic is "
-                                 "12 B/pixel output only; see profiles/ for the PMC capture"},
+                         "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
+                                 "flop each although a correctly rounded sqrt / reproducible exp need 8 / 12 instructions "
+                                 "(DESIGN.md section 5: ~90 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, W, H, args.cpu_columns)

@@ -223,9 +223,14 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
         if (k.type == FT_PR_SLOT) { mn = sd[k.data * FT_BLOCK]; leaf = sl[k.data * FT_BLOCK]; }
         else { mn = prim_eval(k.type, consts + k.data, p); leaf = k.mat; }
     }
-    for (++i; i < end; ++i) {                                          // SdfForm.fs:27
+    // The reference scans the whole list (SdfForm.fs:27).  The list is sorted by LowerBound
+    // (SdfBoundary.fs:267-268; verified NaN-free when the grid is built) and `mn` never grows, so once
+    // `mn > LowerBound - distanceToCenter` (:30) fails for one candidate it fails for every later one
+    // (float subtraction is monotonic): leaving the loop there gives the identical result.
+    for (++i; i < end; ++i) {
         const FtItem it = ld_item(items + i);
-        if (mn > it.lowerBound - distanceToCenter) {                   // :30
+        if (!(mn > it.lowerBound - distanceToCenter)) break;           // :30 false for this and all later candidates
+        {
             const FtChild FT_CONST& k = kids[it.child];
             if (mn > ft_distance(mk3(k.bc[0], k.bc[1], k.bc[2]), p) - k.br) {   // :31 getMinDistance
                 float d; uint32_t l;

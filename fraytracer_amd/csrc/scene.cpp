@@ -84,6 +84,8 @@ std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds
             if (lo < upperBound) cellItems.push_back(FtItem{lo, (uint32_t)i});
         }
         if (cellItems.empty()) { err = "union: a lookup cell has no candidates (the reference would throw at Items.[0])"; return nullptr; }
+        for (const FtItem& it : cellItems)          // the device loop's early exit relies on a totally ordered list
+            if (it.lowerBound != it.lowerBound) { err = "union: NaN boundary"; return nullptr; }
         // Array.sortInPlaceBy (:267-268) is unstable in .NET; ties resolved by input order here.
         std::stable_sort(cellItems.begin(), cellItems.end(),
                          [](const FtItem& a, const FtItem& b) { return a.lowerBound < b.lowerBound; });

@@ -21,7 +21,7 @@ for f, r in rows("trace/**/*kernel_stats.csv"):
 print("== per-dispatch durations of ft_trace_kernel (ns) ==")
 for f, r in rows("trace/**/*kernel_trace.csv"):
     if "ft_trace_kernel" in r.get("Kernel_Name", ""):
-        print(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "VGPR", r.get("VGPR_Count"), "SGPR", r.get("SGPR_Count"),
+        print(r.get("Kernel_Name"), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "VGPR", r.get("VGPR_Count"), "SGPR", r.get("SGPR_Count"),
               "LDS", r.get("LDS_Block_Size"), "grid", r.get("Grid_Size"), "wg", r.get("Workgroup_Size"))
 for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
     acc = defaultdict(list)
