@@ -88,7 +88,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     put(oKids, f.children.data(), f.children.size() * sizeof(FtChild));
     put(oCtr, f.cellCenters.data(), f.cellCenters.size() * 4);
     put(oStart, f.cellStart.data(), f.cellStart.size() * 4);
-    put(oItems, f.items.data(), f.items.size() * sizeof(FtItem));
+    put(oItems, f.items.data(), f.items.size() * sizeof(FtItemRec));
     put(oLights, f.lights.data(), f.lights.size() * sizeof(FtLight));
     put(oMats, f.materials.data(), f.materials.size() * 4);
     FtSceneDev& d = s->dev;
@@ -107,7 +107,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d.children = reinterpret_cast<const FtChild*>(b + oKids);
     d.cellCenters = reinterpret_cast<const float*>(b + oCtr);
     d.cellStart = reinterpret_cast<const uint32_t*>(b + oStart);
-    d.items = reinterpret_cast<const FtItem*>(b + oItems);
+    d.items = reinterpret_cast<const FtItemRec*>(b + oItems);
     d.lights = reinterpret_cast<const FtLight*>(b + oLights);
     d.materials = reinterpret_cast<const float*>(b + oMats);
     return FT_OK;

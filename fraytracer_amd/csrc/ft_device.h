@@ -60,7 +60,18 @@ struct FtChild {                // 8 dwords
     uint32_t pad;
 };
 
-struct FtItem { float lowerBound; uint32_t child; };
+struct FtItem { float lowerBound; uint32_t child; };   // host-side grid build / introspection
+
+// Device form of one (cell, candidate) pair: everything the union loop needs for both pruning tests and
+// for locating the candidate's constants, in ONE 32-byte record (two dwordx4 loads from consecutive
+// addresses; a lane walks its cell's list front to back) instead of item -> child table -> constants.
+struct FtItemRec {              // 8 dwords
+    float lowerBound;           // SpatialLookupItem.LowerBound (SdfBoundary.fs:214)
+    float bc[3]; float br;      // candidate.Boundary
+    uint32_t typeData;          // FtPrim in bits 0..3, constant-pool offset (or slot index) in bits 4..31
+    uint32_t mat;               // material index of a `create solid prim` child
+    uint32_t child;             // index in the union's child list (introspection)
+};
 
 enum FtLightType : uint32_t { FT_LIGHT_DIRECTIONAL = 0, FT_LIGHT_POINT = 1 };
 struct FtLight {                // 8 dwords
@@ -77,7 +88,7 @@ struct FtSceneDev {             // passed by value as kernel argument
     const FtChild* children;
     const float* cellCenters;   // 3 floats per cell
     const uint32_t* cellStart;  // per grid: nCells+1 entries, absolute item indices
-    const FtItem* items;
+    const FtItemRec* items;
     const FtLight* lights;
     const float* materials;     // 3 floats per material
     uint32_t nInstr, nSlots, nLights, fastPath;

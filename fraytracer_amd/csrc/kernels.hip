@@ -38,7 +38,15 @@ __device__ __forceinline__ FtInstr ld_instr(const FtInstr FT_CONST* q) {
     FtInstr r; r.op = q->op; r.dst = q->dst; r.src = q->src; r.type = q->type; r.count = q->count; r.data = q->data;
     r.aux = q->aux; r.flags = q->flags; r.f0 = q->f0; r.f1 = q->f1; r.pad0 = 0; r.pad1 = 0; return r;
 }
-__device__ __forceinline__ FtItem ld_item(const FtItem FT_CONST* q) { FtItem r; r.lowerBound = q->lowerBound; r.child = q->child; return r; }
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+struct ItemRegs { v4f a; v4u b; };   // a = lowerBound, bc.xyz ; b = br, typeData, mat, child
+__device__ __forceinline__ ItemRegs ld_item(const FtItemRec FT_CONST* q) {
+    ItemRegs r;
+    r.a = *reinterpret_cast<const v4f FT_CONST*>(q);
+    r.b = *reinterpret_cast<const v4u FT_CONST*>(reinterpret_cast<const float FT_CONST*>(q) + 4);
+    return r;
+}
 __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
     FtLight r; r.type = q->type; r.v[0] = q->v[0]; r.v[1] = q->v[1]; r.v[2] = q->v[2];
     r.color[0] = q->color[0]; r.color[1] = q->color[1]; r.color[2] = q->color[2]; r.pad = 0.0f; return r;
@@ -211,34 +219,32 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
     cfp ctr = as_const(S.cellCenters) + 3u * cell;
     const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
     const uint32_t FT_CONST* cellStart = as_const(S.cellStart);
-    const FtItem FT_CONST* items = as_const(S.items);
+    const FtItemRec FT_CONST* items = as_const(S.items);
     cfp consts = as_const(S.consts);
     uint32_t i = cellStart[cell];
     const uint32_t end = cellStart[cell + 1];
-    const FtChild FT_CONST* kids = as_const(S.children) + g.childBase;
 
     float mn; uint32_t leaf;
     {                                                                  // Items.[0]  (SdfForm.fs:26)
-        const FtChild FT_CONST& k = kids[items[i].child];
-        if (k.type == FT_PR_SLOT) { mn = sd[k.data * FT_BLOCK]; leaf = sl[k.data * FT_BLOCK]; }
-        else { mn = prim_eval(k.type, consts + k.data, p); leaf = k.mat; }
+        const ItemRegs rec = ld_item(items + i);
+        const uint32_t type = rec.b.y & 15u, data = rec.b.y >> 4;
+        if (type == FT_PR_SLOT) { mn = sd[data * FT_BLOCK]; leaf = sl[data * FT_BLOCK]; }
+        else { mn = prim_eval(type, consts + data, p); leaf = rec.b.z; }
     }
     // The reference scans the whole list (SdfForm.fs:27).  The list is sorted by LowerBound
     // (SdfBoundary.fs:267-268; verified NaN-free when the grid is built) and `mn` never grows, so once
     // `mn > LowerBound - distanceToCenter` (:30) fails for one candidate it fails for every later one
     // (float subtraction is monotonic): leaving the loop there gives the identical result.
     for (++i; i < end; ++i) {
-        const FtItem it = ld_item(items + i);
-        if (!(mn > it.lowerBound - distanceToCenter)) break;           // :30 false for this and all later candidates
-        {
-            const FtChild FT_CONST& k = kids[it.child];
-            if (mn > ft_distance(mk3(k.bc[0], k.bc[1], k.bc[2]), p) - k.br) {   // :31 getMinDistance
-                float d; uint32_t l;
-                if (k.type == FT_PR_SLOT) { d = sd[k.data * FT_BLOCK]; l = sl[k.data * FT_BLOCK]; }
-                else { d = prim_eval(k.type, consts + k.data, p); l = k.mat; }
-                if (d < mn) leaf = l;                                  // SdfObject.fs:41-43
-                mn = ft_min(mn, d);                                    // SdfForm.fs:33
-            }
+        const ItemRegs cur = ld_item(items + i);
+        if (!(mn > cur.a.x - distanceToCenter)) break;                 // :30 false for this and all later candidates
+        if (mn > ft_distance(mk3(cur.a.y, cur.a.z, cur.a.w), p) - __uint_as_float(cur.b.x)) {   // :31 getMinDistance
+            const uint32_t type = cur.b.y & 15u, data = cur.b.y >> 4;
+            float d; uint32_t l;
+            if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
+            else { d = prim_eval(type, consts + data, p); l = cur.b.z; }
+            if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
+            mn = ft_min(mn, d);                                        // SdfForm.fs:33
         }
     }
     outD = mn; outLeaf = leaf;

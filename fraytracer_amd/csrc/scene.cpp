@@ -458,7 +458,16 @@ struct Flattener {
         // global CSR: cellStart has one entry per cell plus a final terminator kept at the back
         if (!out.cellStart.empty()) out.cellStart.pop_back();
         for (size_t ci = 0; ci + 1 < g.cellStart.size(); ++ci) out.cellStart.push_back(itemBase + g.cellStart[ci]);
-        out.items.insert(out.items.end(), g.items.begin(), g.items.end());
+        for (const FtItem& it : g.items) {                              // fuse item + child into the device record
+            const FtChild& ch = out.children[childBase + it.child];
+            if (ch.data >= (1u << 28)) return fail("constant pool exceeds 2^28 floats");
+            FtItemRec r{};
+            r.lowerBound = it.lowerBound;
+            r.bc[0] = ch.bc[0]; r.bc[1] = ch.bc[1]; r.bc[2] = ch.bc[2]; r.br = ch.br;
+            r.typeData = (ch.type & 15u) | (ch.data << 4);
+            r.mat = ch.mat; r.child = it.child;
+            out.items.push_back(r);
+        }
         out.cellStart.push_back((uint32_t)out.items.size());
         const uint32_t gi = (uint32_t)out.grids.size();
         out.grids.push_back(dg);

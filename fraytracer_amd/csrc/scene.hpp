@@ -79,7 +79,7 @@ struct FlatScene {                                            // host copy of ev
     std::vector<FtChild> children;
     std::vector<float> cellCenters;
     std::vector<uint32_t> cellStart;                          // global CSR over all cells of all grids (+1)
-    std::vector<FtItem> items;
+    std::vector<FtItemRec> items;
     std::vector<FtLight> lights;
     std::vector<float> materials;
     uint32_t nSlots = 1;
