@@ -232,12 +232,17 @@ class Device:
 
     _default = {}
     _default_lock = threading.Lock()
+    _serial = 0
 
     def __init__(self, index=0):
         p = C.c_void_p()
         check(lib.ft_ctx_create(int(index), C.byref(p)))
         self._ctx = p
         self.index = int(index)
+        self._scenes = []                      # DeviceScenes created on this context (closed with it)
+        with Device._default_lock:
+            Device._serial += 1
+            self.serial = Device._serial       # cache key for SdfScene._realised (id() values get reused)
 
     @classmethod
     def default(cls, index=0):
@@ -248,6 +253,9 @@ class Device:
 
     def close(self):
         if self._ctx:
+            for s in self._scenes:             # scenes hold device memory of this context: release them first
+                s.close()
+            self._scenes = []
             lib.ft_ctx_destroy(self._ctx)
             self._ctx = None
 
@@ -282,13 +290,14 @@ class Device:
     def scene(self, scene):
         """realise + flatten + upload an SdfScene; cached per device."""
         with scene._lock:
-            got = scene._realised.get(id(self))
-            if got is None:
+            got = scene._realised.get(self.serial)
+            if got is None or got._scene is None:
                 memo = {}
                 obj = realise(scene.Object, self, memo)
                 lights = [realise(l, self, memo) for l in scene.Lights]
                 got = DeviceScene(self, obj, scene.BackgroundColor, lights)
-                scene._realised[id(self)] = got
+                scene._realised[self.serial] = got
+                self._scenes.append(got)
             return got
 
     def selftest_fastmath(self):

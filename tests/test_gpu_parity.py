@@ -230,3 +230,34 @@ def test_extension_defaults_are_the_reference_path(gpu):
     assert_bit_equal(a, b, "spp=1, ao=0")
     with pytest.raises(ft.FrayTracerError):
         ds.render(EPS, LEN, ft.ImageSize(8, 8), cam, spp=3)
+
+
+def test_nan_distances_are_flagged_identically(gpu, oracle):
+    """A degenerate capsule (From == To -> dirInv = 0/0) has a NaN distance.  The reference would spin
+    forever in SdfForm.tryTrace; oracle and kernel both resolve such rays as misses and raise flag bit 0."""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    bad = SdfObject.create(SdfMaterial.createSolid((1, 0, 0)), SdfForm.Primitive.capsule((0, 0, 0), (0, 0, 0), 0.5))
+    scene = SdfScene(bad, syn.BACKGROUND, syn.program_lights())
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, 32, 32)
+    assert_bit_equal(g, o, "NaN scene")
+    assert gst["flags"] & 1 and ocnt["flags"] & 1
+    assert gst["hits_primary"] == ocnt["hits_primary"] == 0
+
+
+def test_empty_and_degenerate_inputs(gpu, oracle):
+    scene, _ = syn.config1()
+    ds, os_ = both(gpu, oracle, scene)
+    out, st = ds.trace_rays(np.zeros((0, 8), np.float32))
+    assert out.shape == (0, 3) and st["rays_primary"] == 0
+    d, m = ds.eval_distance(np.zeros((0, 3), np.float32))
+    assert d.shape == (0,)
+    cam = syn.default_camera()
+    with pytest.raises(ft.FrayTracerError):
+        ds.render(EPS, LEN, ft.ImageSize(0, 8), cam)
+    with pytest.raises(ft.FrayTracerError):
+        ds.render(EPS, LEN, ft.ImageSize(64, 64), cam, x0=60, n_columns=8)          # column range leaves the image
+    # epsilon / length edge cases go through the same code on both sides
+    for eps, length in ((0.01, 0.0), (0.5, 30.0), (1e-4, 12.0)):
+        g, _ = ds.render(eps, length, ft.ImageSize(24, 24), cam)
+        o, _ = os_.render(eps, length, 24, 24, cam.as_array())
+        assert_bit_equal(g, o, f"eps={eps} length={length}")
