@@ -167,3 +167,28 @@ def mixed_nested(seed=7):
                                                       SdfForm.union([SdfForm.Primitive.sphere((0, 0, 0), 3.9), SdfForm.Primitive.sphere((1, 0, 0), 3.9)])])
     objs = [blob, inner_union, carved, clipped] + [random_triangle(rng) for _ in range(4)] + [random_capsule(rng) for _ in range(3)]
     return SdfScene(SdfObject.union(objs), BACKGROUND, program_lights()), ImageSize(96, 96)
+
+
+def combinator_zoo(seed=11):
+    """Every flattener path the other scenes miss: smooth unions with non-sphere runs and with combinator
+    children (SMOOTH_ADD), intersect runs of several primitives of one kind, a union whose first-sorted
+    candidates are combinators, form-level unions under create, three lights."""
+    rng = Rng(seed)
+    P = SdfForm.Primitive
+
+    def sph(r=2.5, lo=0.3, hi=0.8): return P.sphere(rng.pointInBall(r), rng.range(lo, hi))
+    def cap():
+        c = rng.pointInBall(2.5); return P.capsule(c, c + rng.pointOnSphere(rng.range(0.5, 1.5)), rng.range(0.1, 0.3))
+    def tor(): return P.torus(rng.pointInBall(2.5), rng.pointOnSphere(1.0), rng.range(0.3, 0.6), rng.range(0.1, 0.2))
+    def tri():
+        v = rng.pointInBall(2.5); return P.triangle(v, v + rng.pointOnSphere(0.8), v + rng.pointOnSphere(0.8), rng.range(0.05, 0.2))
+
+    blob_mixed = SdfForm.unionSmooth(0.2, [sph(), sph(), cap(), cap(), cap(), tor(), SdfForm.subtract(sph(2.0, 0.8, 1.0), sph(2.0, 0.4, 0.6)),
+                                           tri(), tri(), sph(), SdfForm.intersect([sph(1.0, 1.0, 1.2), sph(1.0, 1.0, 1.2)]), P.box(rng.pointInBall(2.0), (0.3, 0.4, 0.2))])
+    clipped = SdfForm.intersect([SdfForm.union([tor(), tor(), cap(), tri()]), P.sphere((0, 0, 0), 3.0), P.sphere((0.2, 0, 0), 3.1),
+                                 P.box((0, 0, 0), (2.5, 2.5, 2.5)), P.box((0.1, 0, 0), (2.6, 2.4, 2.5)), cap()])
+    objs = [SdfObject.create(_material(rng), blob_mixed), SdfObject.create(_material(rng), clipped),
+            SdfObject.union([SdfObject.create(_material(rng), SdfForm.unionSmooth(0.3, [sph(), sph(), sph()])), random_sphere(rng)]),
+            random_torus(rng), random_triangle(rng)]
+    lights = program_lights() + [SdfLight.point((3.0, 4.0, -6.0), (0.0, 20.0, 30.0))]
+    return SdfScene(SdfObject.union(objs), BACKGROUND, lights), ImageSize(96, 96)

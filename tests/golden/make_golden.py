@@ -25,6 +25,7 @@ CASES = {
     "c3_smooth256_48": (lambda: syn.config3()[0], 48, 48),
     "console_like_300_64": (lambda: syn.console_like(n=300)[0], 64, 64),
     "mixed_nested_48x40": (lambda: syn.mixed_nested()[0], 48, 40),
+    "combinator_zoo_56": (lambda: syn.combinator_zoo()[0], 56, 56),
 }
 
 

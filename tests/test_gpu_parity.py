@@ -121,6 +121,19 @@ def test_mixed_nested_scene(gpu, oracle):
     check_counts(gst, ocnt)
 
 
+def test_combinator_zoo(gpu, oracle):
+    scene, size = syn.combinator_zoo()
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
+    assert_bit_equal(g, o, "zoo image")
+    check_counts(gst, ocnt)
+    assert gst["hits_primary"] > 500 and gst["rays_shadow"] > 500
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-4, 4, (20000, 3)).astype(np.float32)
+    ds, os_ = both(gpu, oracle, scene)
+    O = oracle.Oracle()
+    assert_bit_equal(ds.eval_distance(pts)[0], O.form_distance(O.object_form(os_.object), pts), "zoo distance")
+
+
 def test_non_square_and_ragged_sizes(gpu, oracle):
     scene, _ = syn.config2(seed=11)
     for W, H in [(37, 101), (130, 19), (1, 1), (8, 9)]:
