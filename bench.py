@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="frame is size x size (default: the metric's 4096)")
     ap.add_argument("--spheres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
     ap.add_argument("--cpu-columns", type=int, default=0,
                     help="columns of the frame the CPU oracle is timed on (default: 2 per host thread, at least 32)")
     args = ap.parse_args()
@@ -85,8 +87,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: fraytracer_amd has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W = H = args.size
     if W % (STRIPE * world) != 0:
@@ -100,17 +105,16 @@ def main():
     size = ft.ImageSize(W, H)
     cols = W // world
     slab = torch.empty((cols, H, 3), dtype=torch.float32, device="cuda")
-    gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
-    frame = torch.empty((W, H, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+    recv, frame = ftd.gather_buffers(slab, world, rank, force=args.force_dist)
     tiling = ftd.tiling(W, world, rank, STRIPE)
 
     def step():
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
-        if world > 1:                             # ONE RCCL gather over xGMI + de-interleave on rank 0
-            ftd.gather_frame(slab, world, rank, STRIPE, frame=frame, gathered=gathered)
+        if use_dist:                              # ONE RCCL gather over xGMI + de-interleave on rank 0
+            ftd.gather_frame(slab, world, rank, STRIPE, frame=frame, recv=recv, force=args.force_dist)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -129,7 +133,7 @@ def main():
     cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"]],
                        dtype=torch.int64, device="cuda")
     kms = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
@@ -168,7 +172,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, W, H, args.cpu_columns)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

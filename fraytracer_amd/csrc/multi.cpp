@@ -6,8 +6,9 @@
 // expensive centre of the image is spread over all devices; because the output is column-major
 // (Array2D.fs:30-38) every stripe is one contiguous run of stripe_width*height*3 floats in both
 // the gathered buffer and the final image, so de-interleaving is part of the device->host copy.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library itself is loaded on first use
 
 #include <mutex>
 #include <string>
@@ -34,13 +35,40 @@ CommCache g_cache;
 
 int fail(int code, const std::string& m) { ft_set_error_(code, m.c_str()); return code; }
 
+// RCCL is bound lazily (dlopen) so that single-GPU hosts never load it and a process that already has
+// an RCCL (e.g. PyTorch's bundled copy) keeps exactly one: an already-loaded librccl.so.1 is reused.
+struct Rccl {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+
+bool loadRccl(std::string& err) {
+    if (g_rccl.ok) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.Gather = reinterpret_cast<decltype(g_rccl.Gather)>(dlsym(h, "ncclGather"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.Gather || !g_rccl.GetErrorString) { err = "RCCL lacks ncclGather / ncclCommInitAll"; return false; }
+    g_rccl.ok = true;
+    return true;
+}
+
 bool getComms(const std::vector<int>& devs, std::vector<ncclComm_t>& out, std::string& err) {
+    if (!loadRccl(err)) return false;
     if (g_cache.devices == devs) { out = g_cache.comms; return true; }
-    for (ncclComm_t c : g_cache.comms) ncclCommDestroy(c);
+    for (ncclComm_t c : g_cache.comms) g_rccl.CommDestroy(c);
     g_cache = CommCache{};
     std::vector<ncclComm_t> comms(devs.size());
-    ncclResult_t r = ncclCommInitAll(comms.data(), (int)devs.size(), devs.data());
-    if (r != ncclSuccess) { err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return false; }
+    ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) { err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); return false; }
     g_cache.devices = devs; g_cache.comms = comms;
     out = comms;
     return true;
@@ -95,8 +123,8 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
         p.x0 = 0; p.n_columns = cols; p.stripe_width = S; p.stripe_ranks = n; p.stripe_rank = r;
         int rc = ft_render_device(ctxs[r], scenes[r], cam, &p, send[r]);
         if (rc == FT_OK && n > 1) {
-            ncclResult_t nr = ncclGather(send[r], recv, slab, ncclFloat, 0, comms[r], (hipStream_t)ft_ctx_stream_(ctxs[r]));
-            if (nr != ncclSuccess) { rc = FT_ERR_COMM; errs[r] = std::string("ncclGather: ") + ncclGetErrorString(nr); }
+            ncclResult_t nr = g_rccl.Gather(send[r], recv, slab, ncclFloat, 0, comms[r], (hipStream_t)ft_ctx_stream_(ctxs[r]));
+            if (nr != ncclSuccess) { rc = FT_ERR_COMM; errs[r] = std::string("ncclGather: ") + g_rccl.GetErrorString(nr); }
         } else if (rc != FT_OK) errs[r] = ft_last_error();
         if (rc == FT_OK) { rc = ft_collect_stats(ctxs[r], &sts[r]); if (rc) errs[r] = ft_last_error(); }
         rcs[r] = rc;

@@ -28,20 +28,30 @@ def tiling(width, world, rank, stripe):
     return dict(stripe_width=stripe, stripe_ranks=world, stripe_rank=rank, n_columns=width // world)
 
 
-def gather_frame(slab, world, rank, stripe, frame=None, gathered=None, group=None):
+def gather_buffers(slab, world, rank, force=False):
+    """Pre-allocate (on rank 0) the receive buffer [world, W/world, H, 3] and the frame [W, H, 3]."""
+    if (world == 1 and not force) or rank != 0:
+        return None, None
+    cols, H, C = slab.shape
+    return (torch.empty((world, cols, H, C), dtype=slab.dtype, device=slab.device),
+            torch.empty((cols * world, H, C), dtype=slab.dtype, device=slab.device))
+
+
+def gather_frame(slab, world, rank, stripe, frame=None, recv=None, group=None, force=False):
     """Collect the per-rank slabs [W/world, H, 3] on rank 0 and de-interleave them into the full
-    [W, H, 3] frame.  Returns the frame on rank 0, None elsewhere.  `frame` / `gathered` may be
-    pre-allocated buffers (bench.py reuses them across steps)."""
-    if world == 1:
+    [W, H, 3] frame.  Returns the frame on rank 0, None elsewhere.  `recv` / `frame` may be the buffers of
+    gather_buffers() (bench.py reuses them across steps): the slabs land directly in `recv`, and ONE
+    strided copy de-interleaves them — no intermediate copies."""
+    if world == 1 and not force:          # force: run the collective even in a 1-rank group (rehearsal on one GPU)
         return slab
     cols, H, C = slab.shape
-    if rank == 0 and gathered is None:
-        gathered = [torch.empty_like(slab) for _ in range(world)]
-    dist.gather(slab, gathered if rank == 0 else None, dst=0, group=group)      # the ONE collective of the path
+    if rank == 0 and recv is None:
+        recv, frame = gather_buffers(slab, world, rank, force)
+    dist.gather(slab, list(recv.unbind(0)) if rank == 0 else None, dst=0, group=group)   # the ONE collective of the path
     if rank != 0:
         return None
     if frame is None:
         frame = torch.empty((cols * world, H, C), dtype=slab.dtype, device=slab.device)
-    g = torch.stack(gathered).view(world, cols // stripe, stripe, H, C)          # [rank, stripe j, s, y, c]
+    g = recv.view(world, cols // stripe, stripe, H, C)                                # [rank, stripe j, s, y, c]
     frame.view(cols // stripe, world, stripe, H, C).copy_(g.permute(1, 0, 2, 3, 4))
     return frame
