@@ -41,7 +41,8 @@ def test_blittable_layouts_match_the_reference_records():
 def test_the_library_is_built_in_tree_and_is_not_the_oracle():
     assert _lib.LIB_PATH.startswith(os.path.join(ROOT, "fraytracer_amd"))
     deps = subprocess.check_output(["ldd", _lib.LIB_PATH], text=True)
-    assert "libamdhip64" in deps and "librccl" in deps and "ft_oracle" not in deps
+    assert "libamdhip64" in deps and "ft_oracle" not in deps
+    assert "librccl" not in deps            # RCCL is bound lazily by ft_render_multi (one RCCL per process)
     # the product never references the oracle directory
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fraytracer_amd")):
         for f in files:
