@@ -170,15 +170,19 @@ def main():
                                  "(DESIGN.md section 5: ~90 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, cam, W, H, args.cpu_columns)
+            out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab)
+            out["config"]["max_abs_delta_vs_oracle"] = check["max_abs_delta"]      # second half of the metric: 0.0 = bit-exact
+            out["config"]["pixels_compared_with_oracle"] = check["pixels"]
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(scene, cam, W, H, ncols):
-    """Time the CPU oracle on every (W/ncols)-th column of the same frame, all host threads."""
+def cpu_baseline(scene, cam, W, H, ncols, gpu_frame):
+    """Time the CPU oracle on every (W/ncols)-th column of the same frame, all host threads, and use its
+    output as the checker of the GPU frame on those columns (the oracle is never the thing measured as
+    `value`)."""
     from oracle import binding as ob
     threads = os.cpu_count() or 1
     osc = ob.Oracle().scene(scene)
@@ -186,13 +190,17 @@ def cpu_baseline(scene, cam, W, H, ncols):
         ncols = max(32, 2 * threads)          # the oracle's work queue hands out whole columns (Array2D.fs:32)
     xstep = max(1, W // ncols)
     t0 = time.perf_counter()
-    _, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
+    img, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
     dt = time.perf_counter() - t0
     rays = cnt["rays_primary"] + cnt["rays_shadow"]
+    import numpy as np
+    got = gpu_frame[::xstep].cpu().numpy()
+    delta = float(np.max(np.abs(got.astype(np.float64) - img.astype(np.float64)))) if got.shape == img.shape else float("nan")
+    check = {"max_abs_delta": delta, "pixels": int(img.shape[0] * img.shape[1])}
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"every {xstep}th column of the same {W}x{H} frame ({(W + xstep - 1) // xstep} columns, {rays} rays, {dt:.1f} s); "
                       "oracle = C++ restatement of the F# CPU path, std::function closures, x-column work queue",
-            "seconds": round(dt, 2)}
+            "seconds": round(dt, 2)}, check
 
 
 if __name__ == "__main__":
