@@ -171,22 +171,25 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 // Below 2^-96 (p within 1e-14 of a centre) q is clamped: sqrt(q) and sqrt(2^-96) = 2^-48 are both
 // far below half an ulp of r >= 2^-20, so d = s - r rounds to -r either way — the clamp cannot change
 // the result and ft_sqrt_fast never sees an operand outside [2^-96, 2^32).
+#ifndef FT_UNROLL
+#define FT_UNROLL 4
+#endif
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
     float si = si_;
     asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
-    for (; i + 4 <= count; i += 4) {
-        float4 prm[4];
-        float q[4];
+    for (; i + FT_UNROLL <= count; i += FT_UNROLL) {
+        float4 prm[FT_UNROLL];
+        float q[FT_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) prm[j] = *reinterpret_cast<const float4*>(ldsC + 4 * (i + j));
+        for (int j = 0; j < FT_UNROLL; ++j) prm[j] = *reinterpret_cast<const float4*>(ldsC + 4 * (i + j));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FT_UNROLL; ++j) {
             const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
             q[j] = __builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sum = sum + ft_exp_fast(si * (ft_sqrt_fast(q[j]) - prm[j].w));
+        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast(si * (ft_sqrt_fast(q[j]) - prm[j].w));
     }
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);

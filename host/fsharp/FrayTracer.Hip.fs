@@ -1,0 +1,197 @@
+// FrayTracer.Hip.fs — F# binding of libfraytracer_hip.so for JanWosnitza/FrayTracer.
+//
+// Add this file to src/FrayTracer/FrayTracer.fsproj AFTER Image.fs.  It does not change any reference
+// type: every scene value is paired with the handle of its native twin (`Gpu*` records), built by
+// constructors that have the reference's names, argument order and error behaviour, so a scene script
+// switches from `SdfForm.` / `SdfObject.` / `SdfLight.` to `Hip.SdfForm.` / ... and from
+// `scene |> SdfScene.trace |> Image.render eps len size camera` to `Hip.Image.renderScene eps len size camera scene`.
+// The closures stay available (`.Form`, `.Object`, `.Light`) as the CPU path.
+//
+// NOT COMPILED IN THIS REPOSITORY'S BUILD IMAGE (no .NET toolchain there); the same C ABI calls are
+// exercised by fraytracer_amd/api.py (Python) and host/cpp/FrayTracer.hpp (C++).  Header: include/fraytracer_hip.h.
+namespace FrayTracer.Hip
+
+open System
+open System.Numerics
+open System.Runtime.InteropServices
+open FrayTracer
+
+[<Struct; StructLayout(LayoutKind.Sequential)>]
+type FtRenderParams =
+    { Width : int; Height : int; X0 : int; NColumns : int
+      StripeWidth : int; StripeRanks : int; StripeRank : int; Spp : int
+      Epsilon : float32; Length : float32; AoSamples : int; AoRadius : float32 }
+
+[<Struct; StructLayout(LayoutKind.Sequential)>]
+type FtStats =
+    { RaysPrimary : uint64; RaysShadow : uint64; RaysExt : uint64; HitsPrimary : uint64; HitsShadow : uint64
+      SdfEvals : uint64; Flags : uint64; KernelMs : float32; Reserved : float32; WaveEvals : uint64 }
+
+module Native =
+    [<Literal>]
+    let Lib = "fraytracer_hip"
+
+    [<DllImport(Lib)>] extern int ft_ctx_create(int device, nativeint& ctx)
+    [<DllImport(Lib)>] extern void ft_ctx_destroy(nativeint ctx)
+    [<DllImport(Lib)>] extern nativeint ft_last_error()
+    // the reference's [<Struct>] primitive records are sequential float-only layouts (SdfForm.fs:118-212)
+    [<DllImport(Lib)>] extern int ft_form_sphere(nativeint ctx, SdfForm.Primitive.Sphere& data)
+    [<DllImport(Lib)>] extern int ft_form_capsule(nativeint ctx, SdfForm.Primitive.Capsule& data)
+    [<DllImport(Lib)>] extern int ft_form_torus(nativeint ctx, SdfForm.Primitive.Torus& data)
+    [<DllImport(Lib)>] extern int ft_form_triangle(nativeint ctx, SdfForm.Primitive.Triangle& data)
+    [<DllImport(Lib)>] extern int ft_form_union(nativeint ctx, int[] forms, int n)
+    [<DllImport(Lib)>] extern int ft_form_subtract(nativeint ctx, int a, int b)
+    [<DllImport(Lib)>] extern int ft_form_intersect(nativeint ctx, int[] forms, int n)
+    [<DllImport(Lib)>] extern int ft_form_union_smooth(nativeint ctx, float32 strength, int[] forms, int n)
+    [<DllImport(Lib)>] extern int ft_material_solid(nativeint ctx, Vector3& rgb)
+    [<DllImport(Lib)>] extern int ft_object_create(nativeint ctx, int material, int form)
+    [<DllImport(Lib)>] extern int ft_object_union(nativeint ctx, int[] objects, int n)
+    [<DllImport(Lib)>] extern int ft_object_subtract(nativeint ctx, int obj, int form)
+    [<DllImport(Lib)>] extern int ft_object_intersect(nativeint ctx, int obj, int[] forms, int n)
+    [<DllImport(Lib)>] extern int ft_light_directional(nativeint ctx, Vector3& direction, Vector3& rgb)
+    [<DllImport(Lib)>] extern int ft_light_point(nativeint ctx, Vector3& position, Vector3& rgb)
+    [<DllImport(Lib)>] extern int ft_scene_create(nativeint ctx, int obj, Vector3& background, int[] lights, int n, nativeint& scene)
+    [<DllImport(Lib)>] extern void ft_scene_destroy(nativeint scene)
+    [<DllImport(Lib)>] extern int ft_render(nativeint ctx, nativeint scene, Camera& camera, FtRenderParams& p, nativeint out, FtStats& stats)
+
+    /// one context for the process (GPU 0); there is no CPU fallback inside the library
+    let ctx =
+        lazy (let mutable c = 0n
+              if ft_ctx_create (0, &c) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))
+              c)
+
+    let check (h : int) =
+        if h < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ())) else h
+
+type GpuForm = { Form : FrayTracer.SdfForm; Node : int }
+type GpuMaterial = { Material : FrayTracer.SdfMaterial; Node : int }
+type GpuObject = { Object : FrayTracer.SdfObject; Node : int }
+type GpuLight = { Light : FrayTracer.SdfLight; Node : int }
+type GpuScene = { Object : GpuObject; BackgroundColor : FColor; Lights : GpuLight list }        // Types.fs:74-79
+
+[<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
+module SdfForm =
+    let private c () = Native.ctx.Value
+    let private nodes (forms : GpuForm[]) = forms |> Array.map (fun f -> f.Node)
+
+    module Primitive =
+        let sphere (data : SdfForm.Primitive.Sphere) =                                           // SdfForm.fs:125-135
+            let mutable d = data
+            { Form = SdfForm.Primitive.sphere data; Node = Native.check (Native.ft_form_sphere (Native.ctx.Value, &d)) }
+        let capsule (data : SdfForm.Primitive.Capsule) =                                         // SdfForm.fs:145-170
+            let mutable d = data
+            { Form = SdfForm.Primitive.capsule data; Node = Native.check (Native.ft_form_capsule (Native.ctx.Value, &d)) }
+        let torus (data : SdfForm.Primitive.Torus) =                                             // SdfForm.fs:181-203
+            let mutable d = data
+            { Form = SdfForm.Primitive.torus data; Node = Native.check (Native.ft_form_torus (Native.ctx.Value, &d)) }
+        let triangle (data : SdfForm.Primitive.Triangle) =                                       // SdfForm.fs:214-268
+            let mutable d = data
+            { Form = SdfForm.Primitive.triangle data; Node = Native.check (Native.ft_form_triangle (Native.ctx.Value, &d)) }
+
+    let union (forms : seq<GpuForm>) =                                                           // SdfForm.fs:14-40
+        match forms |> Seq.toArray with
+        | [||] -> failwith "No SdfObjects given."
+        | [| form |] -> form
+        | forms ->
+            { Form = forms |> Seq.map (fun f -> f.Form) |> SdfForm.union
+              Node = Native.check (Native.ft_form_union (c (), nodes forms, forms.Length)) }
+
+    let subtract (a : GpuForm) (b : GpuForm) =                                                   // SdfForm.fs:42-49
+        { Form = SdfForm.subtract a.Form b.Form; Node = Native.check (Native.ft_form_subtract (c (), a.Node, b.Node)) }
+
+    let intersect (forms : seq<GpuForm>) =                                                       // SdfForm.fs:51-67
+        match forms |> Seq.toArray with
+        | [||] -> failwith "No SdfObjects given."
+        | [| form |] -> form
+        | forms ->
+            { Form = forms |> Seq.map (fun f -> f.Form) |> SdfForm.intersect
+              Node = Native.check (Native.ft_form_intersect (c (), nodes forms, forms.Length)) }
+
+    let unionSmooth (strength : float32) (forms : seq<GpuForm>) =                                // SdfForm.fs:69-91
+        match forms |> Seq.toArray with
+        | [||] -> failwithf "blub"
+        | [| sdf |] -> sdf
+        | sdfs ->
+            { Form = sdfs |> Seq.map (fun f -> f.Form) |> SdfForm.unionSmooth strength
+              Node = Native.check (Native.ft_form_union_smooth (c (), strength, nodes sdfs, sdfs.Length)) }
+
+[<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
+module SdfMaterial =
+    let createSolid (color : FColor) =                                                           // SdfMaterial.fs:4-7
+        let mutable rgb = let (FColor v) = color in v
+        { Material = SdfMaterial.createSolid color; Node = Native.check (Native.ft_material_solid (Native.ctx.Value, &rgb)) }
+
+[<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
+module SdfObject =
+    let private c () = Native.ctx.Value
+
+    let create (material : GpuMaterial) (form : GpuForm) : GpuObject =                           // SdfObject.fs:6-10
+        { Object = SdfObject.create material.Material form.Form
+          Node = Native.check (Native.ft_object_create (c (), material.Node, form.Node)) }
+
+    let union (objects : seq<GpuObject>) : GpuObject =                                           // SdfObject.fs:12-48
+        match objects |> Seq.toArray with
+        | [||] -> failwith "No SdfObjects given."
+        | [| o |] -> o
+        | objects ->
+            let nodes = objects |> Array.map (fun o -> o.Node)
+            { Object = objects |> Seq.map (fun o -> o.Object) |> SdfObject.union
+              Node = Native.check (Native.ft_object_union (c (), nodes, nodes.Length)) }
+
+    let subtract (object : GpuObject) (form : GpuForm) : GpuObject =                             // SdfObject.fs:50-54
+        { Object = SdfObject.subtract object.Object form.Form
+          Node = Native.check (Native.ft_object_subtract (c (), object.Node, form.Node)) }
+
+    let intersect (object : GpuObject) (forms : seq<GpuForm>) : GpuObject =                      // SdfObject.fs:56-64
+        let forms = forms |> Seq.toArray
+        let nodes = forms |> Array.map (fun f -> f.Node)
+        { Object = SdfObject.intersect object.Object (forms |> Seq.map (fun f -> f.Form))
+          Node = Native.check (Native.ft_object_intersect (c (), object.Node, nodes, nodes.Length)) }
+
+[<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
+module SdfLight =
+    let directional (direction : Direction) (color : FColor) =                                   // SdfLight.fs:6-21
+        let mutable d = direction
+        let mutable rgb = let (FColor v) = color in v
+        { Light = SdfLight.directional direction color
+          Node = Native.check (Native.ft_light_directional (Native.ctx.Value, &d, &rgb)) }
+
+    let point (position : Position) (color : FColor) =                                           // SdfLight.fs:23-42
+        let mutable p = position
+        let mutable rgb = let (FColor v) = color in v
+        { Light = SdfLight.point position color
+          Node = Native.check (Native.ft_light_point (Native.ctx.Value, &p, &rgb)) }
+
+module Image =
+    /// GPU sibling of `scene |> SdfScene.trace |> Image.render epsilon length imageSize camera`
+    /// (Image.fs:26-35 + SdfScene.fs:7-28).  Result layout = FColor[X,Y] as Array2D.Parallel.init makes it.
+    let renderScene (epsilon : float32) (length : float32) (imageSize : ImageSize) (camera : Camera) (scene : GpuScene) : FColor[,] =
+        let ctx = Native.ctx.Value
+        let lights = scene.Lights |> List.map (fun l -> l.Node) |> List.toArray
+        let mutable bg = let (FColor v) = scene.BackgroundColor in v
+        let mutable handle = 0n
+        Native.check (Native.ft_scene_create (ctx, scene.Object.Node, &bg, lights, lights.Length, &handle)) |> ignore
+        try
+            let image : FColor[,] = Array2D.zeroCreate imageSize.X imageSize.Y
+            let pin = GCHandle.Alloc (image, GCHandleType.Pinned)                                // as Image.fs:77-86 pins its buffer
+            try
+                let mutable cam = camera
+                let mutable p =
+                    { Width = imageSize.X; Height = imageSize.Y; X0 = 0; NColumns = imageSize.X
+                      StripeWidth = imageSize.X; StripeRanks = 1; StripeRank = 0; Spp = 1
+                      Epsilon = epsilon; Length = length; AoSamples = 0; AoRadius = 0f }
+                let mutable stats = Unchecked.defaultof<FtStats>
+                Native.check (Native.ft_render (ctx, handle, &cam, &p, pin.AddrOfPinnedObject (), &stats)) |> ignore
+                image
+            finally
+                pin.Free ()
+        finally
+            Native.ft_scene_destroy handle
+
+    /// the CPU path of the reference on the same scene value (closures)
+    let renderSceneCpu (epsilon : float32) (length : float32) (imageSize : ImageSize) (camera : Camera) (scene : GpuScene) =
+        { FrayTracer.SdfScene.Object = scene.Object.Object
+          BackgroundColor = scene.BackgroundColor
+          Lights = scene.Lights |> List.map (fun l -> l.Light) }
+        |> SdfScene.trace
+        |> Image.render epsilon length imageSize camera
