@@ -3,7 +3,9 @@
 #include "scene.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 
 namespace ft {
 
@@ -68,30 +70,59 @@ std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds
     g->centers.resize(ncells);
     g->cellStart.assign(ncells + 1, 0);
     const float halfDiag = ft_length(g->cellSize * 0.5f);
-    std::vector<FtItem> cellItems;
-    for (int x = 0; x < c; ++x)
-    for (int y = 0; y < c; ++y)
-    for (int z = 0; z < c; ++z) {
-        const size_t ci = ((size_t)x * c + y) * c + z;
-        const f3 center = aabbMin + g->cellSize * 0.5f + g->cellSize * mk3((float)x, (float)y, (float)z);
-        g->centers[ci] = center;
-        float m = maxDistance(bounds[0], center);
-        for (size_t i = 1; i < n; ++i) { const float v = maxDistance(bounds[i], center); if (v < m) m = v; }
-        const float upperBound = m + halfDiag;
-        cellItems.clear();
-        for (size_t i = 0; i < n; ++i) {
-            const float lo = minDistance(bounds[i], center);
-            if (lo < upperBound) cellItems.push_back(FtItem{lo, (uint32_t)i});
+
+    // one x-slab of cells per task (the reference parallelises the same build over y, Array3D.fs:4-14);
+    // Distance(center_i, cellCenter) is computed once and reused for getMaxDistance / getMinDistance —
+    // the same two operations the reference performs, so the values are bit-identical.
+    std::vector<std::vector<FtItem>> slabItems(c);
+    std::vector<std::vector<uint32_t>> slabCounts(c);
+    std::vector<std::string> slabErr(c);
+    auto buildSlab = [&](int x) {
+        std::vector<float> dist(n);
+        std::vector<FtItem> cellItems;
+        slabCounts[x].reserve((size_t)c * c);
+        for (int y = 0; y < c; ++y)
+        for (int z = 0; z < c; ++z) {
+            const size_t ci = ((size_t)x * c + y) * c + z;
+            const f3 center = aabbMin + g->cellSize * 0.5f + g->cellSize * mk3((float)x, (float)y, (float)z);
+            g->centers[ci] = center;
+            for (size_t i = 0; i < n; ++i) dist[i] = ft_distance(bounds[i].center, center);
+            float m = dist[0] + bounds[0].radius;                                   // Seq.min of getMaxDistance (:249-252)
+            for (size_t i = 1; i < n; ++i) { const float v = dist[i] + bounds[i].radius; if (v < m) m = v; }
+            const float upperBound = m + halfDiag;                                  // :253
+            cellItems.clear();
+            for (size_t i = 0; i < n; ++i) {
+                const float lo = dist[i] - bounds[i].radius;                        // getMinDistance (:257)
+                if (lo < upperBound) cellItems.push_back(FtItem{lo, (uint32_t)i});
+            }
+            if (cellItems.empty()) { slabErr[x] = "union: a lookup cell has no candidates (the reference would throw at Items.[0])"; return; }
+            for (const FtItem& it : cellItems)          // the device loop's early exit relies on a totally ordered list
+                if (it.lowerBound != it.lowerBound) { slabErr[x] = "union: NaN boundary"; return; }
+            // Array.sortInPlaceBy (:267-268) is unstable in .NET; ties resolved by input order here.
+            std::stable_sort(cellItems.begin(), cellItems.end(),
+                             [](const FtItem& a, const FtItem& b) { return a.lowerBound < b.lowerBound; });
+            slabCounts[x].push_back((uint32_t)cellItems.size());
+            slabItems[x].insert(slabItems[x].end(), cellItems.begin(), cellItems.end());
         }
-        if (cellItems.empty()) { err = "union: a lookup cell has no candidates (the reference would throw at Items.[0])"; return nullptr; }
-        for (const FtItem& it : cellItems)          // the device loop's early exit relies on a totally ordered list
-            if (it.lowerBound != it.lowerBound) { err = "union: NaN boundary"; return nullptr; }
-        // Array.sortInPlaceBy (:267-268) is unstable in .NET; ties resolved by input order here.
-        std::stable_sort(cellItems.begin(), cellItems.end(),
-                         [](const FtItem& a, const FtItem& b) { return a.lowerBound < b.lowerBound; });
-        g->cellStart[ci] = (uint32_t)g->items.size();
-        g->items.insert(g->items.end(), cellItems.begin(), cellItems.end());
+    };
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (hw > 1 && ncells * n > 200000 && c > 1) {
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < std::min<unsigned>(hw, (unsigned)c); ++t)
+            pool.emplace_back([&]() { for (int x; (x = next.fetch_add(1)) < c;) buildSlab(x); });
+        for (auto& t : pool) t.join();
+    } else {
+        for (int x = 0; x < c; ++x) buildSlab(x);
     }
+    // stitch the slabs together in x order: CSR offsets, then the items behind one another
+    size_t ci = 0, total = 0;
+    for (int x = 0; x < c; ++x) {
+        if (!slabErr[x].empty()) { err = slabErr[x]; return nullptr; }
+        for (uint32_t cnt : slabCounts[x]) { g->cellStart[ci++] = (uint32_t)total; total += cnt; }
+    }
+    g->items.reserve(total);
+    for (int x = 0; x < c; ++x) g->items.insert(g->items.end(), slabItems[x].begin(), slabItems[x].end());
     g->cellStart[ncells] = (uint32_t)g->items.size();
     return g;
 }
