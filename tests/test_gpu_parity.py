@@ -274,3 +274,34 @@ def test_empty_and_degenerate_inputs(gpu, oracle):
         g, _ = ds.render(eps, length, ft.ImageSize(24, 24), cam)
         o, _ = os_.render(eps, length, 24, 24, cam.as_array())
         assert_bit_equal(g, o, f"eps={eps} length={length}")
+
+
+# ---- BASELINE.json sizes -----------------------------------------------------------------------------------
+def test_config2_full_size_against_oracle(gpu, oracle):
+    """configs[1] at its stated 1024x1024, every pixel against the oracle."""
+    scene, size = syn.config2()
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
+    assert_bit_equal(g, o, "C2 1024^2")
+    check_counts(gst, ocnt)
+
+
+def test_config3_full_frame_properties_and_sampled_oracle(gpu, oracle):
+    """configs[2] at 4096x4096: (a) every 64th column against the oracle, (b) the frame equals the
+    concatenation of 8 interleaved-stripe renders (what 8 GPUs would produce), (c) counters add up."""
+    scene, size = syn.config3()
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    W = H = size.X
+    full, st = ds.render(EPS, LEN, size, cam)
+    want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array(), xstep=64)
+    assert_bit_equal(full[::64], want, "C3 4096^2, every 64th column")
+    assert st["rays_primary"] == W * H and st["flags"] == 0
+    S, R = 16, 8
+    shadow = 0
+    for r in range(R):
+        slab, sst = ds.render(EPS, LEN, size, cam, stripe_width=S, stripe_ranks=R, stripe_rank=r, n_columns=W // R)
+        shadow += sst["rays_shadow"]
+        got = slab.reshape(W // R // S, S, H, 3)
+        ref = full.reshape(W // (R * S), R, S, H, 3)[:, r]
+        assert_bit_equal(got, ref, f"stripe rank {r}")
+    assert shadow == st["rays_shadow"]
