@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
     ap.add_argument("--cpu-columns", type=int, default=0,
-                    help="columns of the frame the CPU oracle is timed on (default: 2 per host thread, at least 32)")
+                    help="columns of the frame the CPU oracle is timed on (default: 16 per usable host CPU, at least 32)")
     args = ap.parse_args()
 
     import numpy as np
@@ -179,15 +179,28 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes
+    give a job 16 of the host's 256 hardware threads through cpu.max, which os.cpu_count() does not see)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(scene, cam, W, H, ncols, gpu_frame):
     """Time the CPU oracle on every (W/ncols)-th column of the same frame, all host threads, and use its
     output as the checker of the GPU frame on those columns (the oracle is never the thing measured as
     `value`)."""
     from oracle import binding as ob
-    threads = os.cpu_count() or 1
+    threads = host_cpu_share()
     osc = ob.Oracle().scene(scene)
     if ncols <= 0:
-        ncols = max(32, 2 * threads)          # the oracle's work queue hands out whole columns (Array2D.fs:32)
+        ncols = max(32, 16 * threads)         # the oracle's work queue hands out whole columns (Array2D.fs:32)
     xstep = max(1, W // ncols)
     t0 = time.perf_counter()
     img, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
