@@ -1,0 +1,187 @@
+"""A second, independent restatement of the hot path — vectorised numpy float32, written from the F# text,
+sharing no code with oracle/ft_oracle.cpp — for the scene family sphere / unionSmooth-of-spheres with
+directional and point lights.  It must agree with the oracle BIT FOR BIT on whole images.  (The reference
+has no fixtures and cannot run here; two independent restatements agreeing is the strongest pin available
+besides the hand-derived known answers.)  exp / log are taken from the oracle's array entry points — they
+are our own fixed algorithms, checked separately below against an exact rational evaluation.
+
+numpy float32 +, -, *, /, sqrt are IEEE correctly rounded, and numpy never contracts a*b+c.
+"""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from fraytracer_amd import synthetic as syn
+from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfLight, SdfScene
+from helpers import assert_bit_equal
+
+F = np.float32
+
+
+def dot(a, b):                      # Vector3.Dot: (x*x' + y*y') + z*z'
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def length(a):
+    return np.sqrt(dot(a, a))
+
+
+def normalize(a):                   # v / Length (true division per component)
+    return a / length(a)[..., None]
+
+
+class NumpyTracer:
+    """Image.render for: Object = create(solid, sphere) or create(solid, unionSmooth(k, spheres))."""
+
+    def __init__(self, oracle, centers, radii, strength, color, bg, lights):
+        self.o = oracle
+        self.C = np.asarray(centers, F).reshape(-1, 3)
+        self.R = np.asarray(radii, F).reshape(-1)
+        self.k = None if strength is None else F(strength)
+        self.color, self.bg, self.lights = np.asarray(color, F), np.asarray(bg, F), lights
+
+    def distance(self, p):          # SdfForm.fs:129 / :75-82
+        if self.k is None:
+            d = self.C[0] - p
+            return np.sqrt(dot(d, d)) - self.R[0]
+        si = F(-1.0) / self.k                                   # strengthInverse
+        s = np.zeros(p.shape[0], F)
+        for i in range(self.C.shape[0]):                        # sequential float32 sum in child order
+            d = self.C[i] - p
+            dist = np.sqrt(dot(d, d)) - self.R[i]
+            s = s + self.o.expf(si * dist)
+        with np.errstate(all="ignore"):
+            return -self.o.logf(s) * self.k
+
+    def march(self, origin, direction, length_, eps):
+        """SdfForm.tryTrace over a batch: returns hit mask, hit origins."""
+        n = origin.shape[0]
+        o, L = origin.copy(), length_.copy()
+        alive = np.ones(n, bool)
+        hit = np.zeros(n, bool)
+        for _ in range(100000):
+            alive &= ~(L <= 0)                                  # SdfForm.fs:94
+            idx = np.flatnonzero(alive)
+            if idx.size == 0:
+                break
+            with np.errstate(all="ignore"):
+                d = self.distance(o[idx])
+            h = d < eps                                         # :98
+            hit[idx[h]] = True
+            alive[idx[h]] = False
+            mv = idx[~h]
+            with np.errstate(all="ignore"):
+                o[mv] = o[mv] + direction[mv] * d[~h][:, None]  # Ray.move (Ray.fs:9-13)
+                L[mv] = L[mv] - d[~h]
+        return hit, o
+
+    def render(self, W, H, cam, eps=F(syn.EPSILON), length_=F(syn.RAY_LENGTH)):
+        pos, fw, up, rt = cam[0:3], cam[3:6], cam[6:9], cam[9:12]
+        m = F(max(W, H))
+        xs, ys = np.meshgrid(np.arange(W, dtype=F), np.arange(H, dtype=F), indexing="ij")
+        px, py = (xs / m).reshape(-1), (ys / m).reshape(-1)     # Image.fs:20-23
+        d = fw + (px - F(0.5))[:, None] * rt + (py - F(0.5))[:, None] * up     # Camera.fs:48-50
+        d = normalize(d)
+        n = d.shape[0]
+        o = np.tile(pos, (n, 1))
+        hit, ho = self.march(o, d, np.full(n, length_, F), eps)
+        out = np.tile(self.bg, (n, 1))                          # SdfScene.fs:10
+        hi = np.flatnonzero(hit)
+        hd = d[hi]
+        p = ho[hi] + hd * (-eps)                                # Ray.get (-eps)  (SdfForm.fs:115, SdfObject.fs:73)
+        h = eps * F(0.125)
+        with np.errstate(all="ignore"):
+            g = np.stack([self.distance(p + np.array([h, 0, 0], F)), self.distance(p + np.array([0, h, 0], F)),
+                          self.distance(p + np.array([0, 0, h], F))], 1) - self.distance(p)[:, None]
+            nrm = normalize(g)                                  # SdfForm.fs:107-112
+        lc = np.tile(self.bg, (hi.size, 1))                     # SdfScene.fs:12
+        for kind, v, col in self.lights:
+            v, col = np.asarray(v, F), np.asarray(col, F)
+            if kind == "directional":                           # SdfLight.fs:6-21
+                ldir = np.tile(normalize((F(0) - v)[None, :])[0], (hi.size, 1))
+                sdir, slen, inten = ldir, np.full(hi.size, F(1000.0), F), np.tile(col, (hi.size, 1))
+            else:                                               # SdfLight.fs:23-42
+                diff = v - p
+                ldir = normalize(diff)
+                d2 = dot(diff, diff)
+                sdir, slen, inten = diff / d2[:, None], np.sqrt(d2), col[None, :] / d2[:, None]
+            with np.errstate(all="ignore"):
+                cos = dot(nrm, ldir)                            # SdfScene.fs:15
+            lit = np.flatnonzero(cos > 0)                       # :17 (NaN normal -> False)
+            shadowed, _ = self.march(p[lit], sdir[lit], slen[lit], eps)
+            free = lit[~shadowed]
+            lc[free] = lc[free] + inten[free] * cos[free][:, None]          # :23
+        piInv = F(1) / F(3.14159274)
+        out[hi] = self.color * (lc * piInv)                     # :28
+        return out.reshape(W, H, 3)
+
+
+def build(oracle, n, strength, lights, seed):
+    rng = syn.Rng(seed)
+    C = [rng.pointInBall(3.0) for _ in range(n)]
+    R = [rng.range(0.3, 0.9) for _ in range(n)]
+    forms = [SdfForm.Primitive.sphere(c, r) for c, r in zip(C, R)]
+    form = forms[0] if strength is None else SdfForm.unionSmooth(strength, forms)
+    color = (0.9, 0.6, 0.3)
+    lmirror = [SdfLight.directional(v, c) if k == "directional" else SdfLight.point(v, c) for k, v, c in lights]
+    scene = SdfScene(SdfObject.create(SdfMaterial.createSolid(color), form), syn.BACKGROUND, lmirror)
+    return scene, NumpyTracer(oracle, C, R, strength, color, syn.BACKGROUND, lights)
+
+
+LIGHTS = [("directional", (-0.5, -1.0, 1.0), (0.5, 0.5, 0.5)), ("point", (-0.5, 0.0, -5.0), (10.0, 0.0, 0.0))]
+
+
+@pytest.mark.parametrize("n,strength,lights,size", [(1, None, [], (64, 64)), (1, None, LIGHTS, (48, 40)),
+                                                    (12, 0.25, LIGHTS, (40, 40)), (20, 0.5, LIGHTS[:1], (36, 44))])
+def test_numpy_restatement_agrees_with_oracle(oracle, n, strength, lights, size):
+    scene, tracer = build(oracle, n, strength, lights, seed=100 + n)
+    cam = syn.default_camera().as_array()
+    W, H = size
+    want, cnt = oracle.Oracle().scene(scene).render(syn.EPSILON, syn.RAY_LENGTH, W, H, cam)
+    got = tracer.render(W, H, cam)
+    assert cnt["hits_primary"] > 10
+    assert_bit_equal(got, want, f"numpy vs oracle, {n} spheres")
+
+
+# ---- the fixed exp algorithm, evaluated exactly --------------------------------------------------------------
+def _f32(x):
+    """round a Fraction to the nearest float32 (ties to even), as a Fraction; normal range only"""
+    if x == 0:
+        return Fraction(0)
+    s, a = (1, x) if x > 0 else (-1, -x)
+    e = 0
+    while a >= 2: a /= 2; e += 1
+    while a < 1: a *= 2; e -= 1
+    scaled = a * (1 << 23)
+    fl = scaled.numerator // scaled.denominator
+    rem = scaled - fl
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1):
+        fl += 1
+    return s * Fraction(fl, 1 << 23) * (Fraction(2) ** e)
+
+
+def _exp_exact_algorithm(x):
+    """oracle/ft_oracle.cpp orc_expf_impl and csrc/ft_math.h ft_exp, every rounding done in exact rationals"""
+    c = [float.fromhex(h) for h in ("0x1.0p-1", "0x1.5554dcp-3", "0x1.55551ap-5", "0x1.120b6ep-7", "0x1.6d110ap-10")]
+    X = Fraction(float(x))
+    fma = lambda a, b, cc: _f32(Fraction(a) * Fraction(b) + Fraction(cc))
+    tm = fma(X, float.fromhex("0x1.715476p+0"), 12582912.0)
+    n = _f32(tm - 12582912)
+    r = fma(n, -float.fromhex("0x1.62e4p-1"), X)
+    r = fma(n, -float.fromhex("0x1.7f7d1cp-20"), r)
+    q = Fraction(c[4])
+    for k in (3, 2, 1, 0):
+        q = fma(q, r, c[k])
+    r2 = _f32(r * r)
+    s = fma(q, r2, r)
+    p = _f32(s + 1)
+    return float(p * Fraction(2) ** int(n))
+
+
+def test_exp_matches_exact_rational_evaluation(oracle):
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.uniform(-80, 80, 300), rng.uniform(-1, 1, 200), [0.0, 0.5, -0.5, 1.0, -17.328680, 0.34657359]]).astype(F)
+    got = oracle.expf(xs)
+    want = np.array([_exp_exact_algorithm(x) for x in xs], F)
+    assert_bit_equal(got, want, "exp algorithm, exact evaluation")
