@@ -37,11 +37,6 @@ struct ft_ctx {
     FtStatsDev* dStats = nullptr;
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
     void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
-    // host-output pipeline of ft_render: copy stream, two pinned staging buffers, per-chunk events
-    hipStream_t copyStream = nullptr;
-    void* stage[2] = {nullptr, nullptr}; size_t stageBytes = 0;
-    hipEvent_t evCopy[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> evChunk;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
 };
@@ -215,9 +210,6 @@ void ft_ctx_destroy(ft_ctx* c) {
         for (auto& p : c->eventPool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (c->scratch) (void)hipFree(c->scratch);
         if (c->planes) (void)hipFree(c->planes);
-        for (int i = 0; i < 2; ++i) { if (c->stage[i]) (void)hipHostFree(c->stage[i]); if (c->evCopy[i]) (void)hipEventDestroy(c->evCopy[i]); }
-        for (hipEvent_t e : c->evChunk) (void)hipEventDestroy(e);
-        if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
         if (c->dCounter) (void)hipFree(c->dCounter);
         if (c->dStats) (void)hipFree(c->dStats);
         if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -388,56 +380,14 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
     return FT_OK;
 }
 
-// Host-output render.  Large contiguous frames are pipelined in column chunks: while the kernel of chunk
-// k+1 runs, chunk k is DMA-copied into a pinned staging buffer on a second stream and from there into the
-// caller's (pageable, e.g. GC-pinned F#) array, so only the last chunk's transfer is exposed.  Pixels are
-// independent, so chunking cannot change a value (tests compare tiled and monolithic renders).
 int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, float* out, ft_stats* st) {
     int rc = requireDevice(c); if (rc) return rc;
     if (!out) return setErr(FT_ERR_INVALID, "null output");
     if ((rc = checkParams(p))) return rc;
-    const size_t colBytes = (size_t)p->height * 3 * sizeof(float);
-    const size_t bytes = (size_t)p->n_columns * colBytes;
+    const size_t bytes = (size_t)p->n_columns * p->height * 3 * sizeof(float);
     if ((rc = ensureScratch(c, bytes))) return rc;
-    const bool pipelined = p->stripe_ranks == 1 && p->spp == 1 && bytes >= ((size_t)48 << 20) && p->n_columns >= 128;
-    if (!pipelined) {
-        if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
-        HIP_TRY(hipMemcpyAsync(out, c->scratch, bytes, hipMemcpyDeviceToHost, c->stream));
-        return ft_collect_stats(c, st);
-    }
-    const int nChunks = 6;
-    const int chunkCols = ((p->n_columns + nChunks - 1) / nChunks + 7) & ~7;
-    const size_t chunkBytes = (size_t)chunkCols * colBytes;
-    if (!c->copyStream) HIP_TRY(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) if (!c->evCopy[i]) HIP_TRY(hipEventCreateWithFlags(&c->evCopy[i], hipEventDisableTiming));
-    if (chunkBytes > c->stageBytes) {
-        for (int i = 0; i < 2; ++i) { if (c->stage[i]) { HIP_TRY(hipHostFree(c->stage[i])); c->stage[i] = nullptr; } }
-        c->stageBytes = 0;
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&c->stage[i], chunkBytes, hipHostMallocDefault));
-        c->stageBytes = chunkBytes;
-    }
-    std::vector<int> first, count;
-    for (int c0 = 0; c0 < p->n_columns; c0 += chunkCols) { first.push_back(c0); count.push_back(std::min(chunkCols, p->n_columns - c0)); }
-    while (c->evChunk.size() < first.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->evChunk.push_back(e); }
-    unsigned char* dev = static_cast<unsigned char*>(c->scratch);
-    auto launchChunk = [&](size_t k) -> int {
-        ft_render_params pk = *p;
-        pk.x0 = p->x0 + first[k]; pk.n_columns = count[k]; pk.stripe_width = count[k];
-        int r = ft_render_device(c, s, cam, &pk, dev + (size_t)first[k] * colBytes);
-        if (r) return r;
-        HIP_TRY(hipEventRecord(c->evChunk[k], c->stream));
-        return FT_OK;
-    };
-    if ((rc = launchChunk(0))) return rc;
-    for (size_t k = 0; k < first.size(); ++k) {
-        if (k + 1 < first.size() && (rc = launchChunk(k + 1))) return rc;       // keep the GPU busy with the next chunk
-        const size_t off = (size_t)first[k] * colBytes, n = (size_t)count[k] * colBytes;
-        HIP_TRY(hipStreamWaitEvent(c->copyStream, c->evChunk[k], 0));
-        HIP_TRY(hipMemcpyAsync(c->stage[k & 1], dev + off, n, hipMemcpyDeviceToHost, c->copyStream));
-        HIP_TRY(hipEventRecord(c->evCopy[k & 1], c->copyStream));
-        HIP_TRY(hipEventSynchronize(c->evCopy[k & 1]));
-        memcpy(reinterpret_cast<unsigned char*>(out) + off, c->stage[k & 1], n);
-    }
+    if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->scratch, bytes, hipMemcpyDeviceToHost, c->stream));
     return ft_collect_stats(c, st);
 }
 

@@ -38,6 +38,7 @@ for name, scene, n in cases:
     st = ds.collect_stats()
     rays = (st["rays_primary"] + st["rays_shadow"]) / reps
     ms = st["kernel_ms"] / reps
+    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam)      # first call allocates staging buffers
     t0 = time.perf_counter()
     img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam)      # host output: includes the device->host copy
     t_host = time.perf_counter() - t0
