@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
     ap.add_argument("--cpu-columns", type=int, default=0,
-                    help="columns of the frame the CPU oracle is timed on (default: 16 per usable host CPU, at least 32)")
+                    help="columns of the frame the CPU oracle is timed on (default: 32 per usable host CPU, at least 32)")
     args = ap.parse_args()
 
     import numpy as np
@@ -200,7 +200,7 @@ def cpu_baseline(scene, cam, W, H, ncols, gpu_frame):
     threads = host_cpu_share()
     osc = ob.Oracle().scene(scene)
     if ncols <= 0:
-        ncols = max(32, 16 * threads)         # the oracle's work queue hands out whole columns (Array2D.fs:32)
+        ncols = max(32, 32 * threads)         # the oracle's work queue hands out whole columns (Array2D.fs:32)
     xstep = max(1, W // ncols)
     t0 = time.perf_counter()
     img, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
