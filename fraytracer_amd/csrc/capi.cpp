@@ -3,7 +3,6 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -128,7 +127,6 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     int perCU = 0;
     HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.spp != 1u || a.aoSamples != 0u, ldsBytes(s), &perCU));
     perCU = std::max(1, std::min(perCU, 8));
-    if (const char* e = getenv("FT_BLOCKS_PER_CU")) perCU = std::max(1, std::min(perCU, atoi(e)));   // tuning experiments only
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
@@ -137,7 +135,6 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     // pixels) and 2.6e5 atomics per 4096^2 frame are far below the rate one counter sustains
     (void)waves;
     uint64_t chunk = 64;
-    if (const char* e = getenv("FT_CHUNK")) chunk = std::max(64, atoi(e)) & ~63;                       // tuning experiments only
     a.chunk = (uint32_t)chunk;
     a.counter = c->dCounter;
     a.stats = c->dStats;
