@@ -121,21 +121,19 @@ __device__ __forceinline__ uint32_t prim_stride(uint32_t type) {
 // Guarded fast forms of sqrt and exp for the uniform smooth-union loop.  Both give bit-identical
 // results to sqrtf / ft_exp on their stated ranges (proved by exhaustion over every float in the
 // range: ft_selftest_fastmath, tests/test_gpu_parity.py); callers fall back outside.
-//   ft_sqrt_fast: q in [2^-96, 2^100].  v_rsq_f32 seed + one coupled Newton step on (s, h) + one
-//                 residual correction: 1 quarter-rate + 7 full-rate ops, no compares/selects
-//                 (hipcc's IEEE sqrtf is ~17 instructions with denormal scaling and fix-ups).
+//   ft_sqrt_fast: q in [2^-96, 2^100].  v_rsq_f32 seed, s = q*r, one residual correction s + (q - s*s)*(r/2):
+//                 1 quarter-rate + 4 full-rate ops, no compares/selects (hipcc's IEEE sqrtf is ~17
+//                 instructions with denormal scaling and fix-ups; the classic coupled-Newton form needs 8).
+//                 x*rsq(x) alone is wrong for 29 % of the range, raw v_sqrt_f32 for 15 %; this form for none.
 //   ft_exp_fast:  t in [-2.9e6, 88]: no NaN test and no clamps; n is taken from the mantissa of the
 //                 magic-number sum (one integer subtract) instead of v_rndne + v_cvt (both half rate).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ft_sqrt_fast(float x) {
-    const float r = __builtin_amdgcn_rsqf(x);
-    float s = x * r;
-    float h = 0.5f * r;
-    const float e = fmaf(-h, s, 0.5f);
-    h = fmaf(h, e, h);
-    s = fmaf(s, e, s);
-    const float d = fmaf(-s, s, x);
-    return fmaf(d, h, s);
+    const float r = __builtin_amdgcn_rsqf(x);      // v_rsq_f32
+    const float s = x * r;                          // ~1 ulp estimate of sqrt(x)
+    const float h = 0.5f * r;                       // ~1/(2 sqrt(x))
+    const float d = fmaf(-s, s, x);                 // residual x - s^2 (one rounding)
+    return fmaf(d, h, s);                           // s + d/(2 sqrt(x)): correctly rounded on the whole proved range
 }
 
 __device__ __forceinline__ float ft_exp_fast(float x) {
@@ -178,7 +176,7 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 // instruction-fetch lines (measured: 68.6 vs 74.5 ms per C3 frame between phases).  FT_LOOP_PHASE pins the
 // placement (64-byte boundary + FT_LOOP_PAD s_nops) so that unrelated edits cannot flip the mode.
 #ifndef FT_LOOP_PAD
-#define FT_LOOP_PAD 7
+#define FT_LOOP_PAD 5
 #endif
 
 #define FT_STR2(x) #x
