@@ -141,14 +141,13 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
     const float n = tm - 12582912.0f;
     float r = fmaf(n, -0x1.62e4p-1f, x);
     r = fmaf(n, -0x1.7f7d1cp-20f, r);
-    float q = 0x1.6d110ap-10f;
-    q = fmaf(q, r, 0x1.120b6ep-7f);
-    q = fmaf(q, r, 0x1.55551ap-5f);
-    q = fmaf(q, r, 0x1.5554dcp-3f);
-    q = fmaf(q, r, 0x1.0p-1f);
-    const float r2 = r * r;
-    const float sres = fmaf(q, r2, r);
-    const float pz = sres + 1.0f;
+    float pz = 0x1.6d7538p-10f;
+    pz = fmaf(pz, r, 0x1.120b72p-7f);
+    pz = fmaf(pz, r, 0x1.5554b8p-5f);
+    pz = fmaf(pz, r, 0x1.5554dcp-3f);
+    pz = fmaf(pz, r, 0x1.0p-1f);
+    pz = fmaf(pz, r, 1.0f);
+    pz = fmaf(pz, r, 1.0f);
     // v_ldexp_f32 rounds subnormal results correctly and flushes to 0 / inf beyond, so no clamps
     return __builtin_amdgcn_ldexpf(pz, (int)(__float_as_uint(tm) - 0x4B400000u));
 }
@@ -176,7 +175,7 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 // instruction-fetch lines (measured: 68.6 vs 74.5 ms per C3 frame between phases).  FT_LOOP_PHASE pins the
 // placement (64-byte boundary + FT_LOOP_PAD s_nops) so that unrelated edits cannot flip the mode.
 #ifndef FT_LOOP_PAD
-#define FT_LOOP_PAD 5
+#define FT_LOOP_PAD 3
 #endif
 
 #define FT_STR2(x) #x

@@ -163,19 +163,16 @@ def _f32(x):
 
 def _exp_exact_algorithm(x):
     """oracle/ft_oracle.cpp orc_expf_impl and csrc/ft_math.h ft_exp, every rounding done in exact rationals"""
-    c = [float.fromhex(h) for h in ("0x1.0p-1", "0x1.5554dcp-3", "0x1.55551ap-5", "0x1.120b6ep-7", "0x1.6d110ap-10")]
+    c = [float.fromhex(h) for h in ("0x1.6d7538p-10", "0x1.120b72p-7", "0x1.5554b8p-5", "0x1.5554dcp-3", "0x1.0p-1", "0x1.0p+0", "0x1.0p+0")]
     X = Fraction(float(x))
     fma = lambda a, b, cc: _f32(Fraction(a) * Fraction(b) + Fraction(cc))
     tm = fma(X, float.fromhex("0x1.715476p+0"), 12582912.0)
     n = _f32(tm - 12582912)
     r = fma(n, -float.fromhex("0x1.62e4p-1"), X)
     r = fma(n, -float.fromhex("0x1.7f7d1cp-20"), r)
-    q = Fraction(c[4])
-    for k in (3, 2, 1, 0):
-        q = fma(q, r, c[k])
-    r2 = _f32(r * r)
-    s = fma(q, r2, r)
-    p = _f32(s + 1)
+    p = Fraction(c[0])
+    for k in range(1, 7):                                   # Horner, degree 6
+        p = fma(p, r, c[k])
     return float(p * Fraction(2) ** int(n))
 
 
