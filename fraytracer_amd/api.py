@@ -301,9 +301,9 @@ class Device:
             return got
 
     def selftest_fastmath(self):
-        m = (C.c_uint64 * 2)()
+        m = (C.c_uint64 * 3)()
         check(lib.ft_selftest_fastmath(self._ctx, m))
-        return {"sqrt": int(m[0]), "exp": int(m[1])}
+        return {"sqrt": int(m[0]), "exp": int(m[1]), "exp_near": int(m[2])}
 
     def math_eval(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -94,7 +94,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d = FtSceneDev{};
     d.nInstr = (uint32_t)f.instr.size(); d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
-    d.nStage = f.nStage;
+    d.nStage = f.nStage; d.nearR2 = f.nearR2;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));
@@ -439,20 +439,23 @@ int ft_math_eval(ft_ctx* c, int32_t op, const float* x, const float* y, int64_t 
     return FT_OK;
 }
 
-int ft_selftest_fastmath(ft_ctx* c, uint64_t mismatches[2]) {
+int ft_selftest_fastmath(ft_ctx* c, uint64_t mismatches[3]) {
     int rc = requireDevice(c); if (rc) return rc;
     if (!mismatches) return setErr(FT_ERR_INVALID, "null output");
     if ((rc = ensureScratch(c, 256))) return rc;
     unsigned long long* d = static_cast<unsigned long long*>(c->scratch);
-    HIP_TRY(hipMemsetAsync(d, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(d, 0, 24, c->stream));
     // sqrt: every float in [2^-96, 2^100]; exp: every float in [-2.9e6, -0] and [+0, 88]
     HIP_TRY(ft_launch_selftest(0, 0x0F800000u, 0x71800000u, d, c->stream));
     HIP_TRY(ft_launch_selftest(1, 0x80000000u, 0xCA310080u, d + 1, c->stream));
     HIP_TRY(ft_launch_selftest(1, 0x00000000u, 0x42B00000u, d + 1, c->stream));
-    unsigned long long h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+    // exponent-add form of exp ("near" regime): every float in [-87, -0] and [+0, 88]
+    HIP_TRY(ft_launch_selftest(2, 0x80000000u, 0xC2AE0000u, d + 2, c->stream));
+    HIP_TRY(ft_launch_selftest(2, 0x00000000u, 0x42B00000u, d + 2, c->stream));
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    mismatches[0] = h[0]; mismatches[1] = h[1];
+    mismatches[0] = h[0]; mismatches[1] = h[1]; mismatches[2] = h[2];
     return FT_OK;
 }
 

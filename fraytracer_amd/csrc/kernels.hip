@@ -136,6 +136,7 @@ __device__ __forceinline__ float ft_sqrt_fast(float x) {
     return fmaf(d, h, s);                           // s + d/(2 sqrt(x)): correctly rounded on the whole proved range
 }
 
+template <bool NEAR>
 __device__ __forceinline__ float ft_exp_fast(float x) {
     const float tm = fmaf(x, 0x1.715476p+0f, 12582912.0f);
     const float n = tm - 12582912.0f;
@@ -148,7 +149,10 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
     pz = fmaf(pz, r, 0x1.0p-1f);
     pz = fmaf(pz, r, 1.0f);
     pz = fmaf(pz, r, 1.0f);
-    // v_ldexp_f32 rounds subnormal results correctly and flushes to 0 / inf beyond, so no clamps
+    // NEAR (x in [-87, 88], result a normal number): 2^n is applied by adding n, which sits in the low
+    // mantissa bits of tm, to the exponent field — one v_lshl_add_u32 instead of v_sub_u32 + v_ldexp_f32.
+    if (NEAR) return __uint_as_float((__float_as_uint(tm) << 23) + __float_as_uint(pz));
+    // otherwise v_ldexp_f32: rounds subnormal results correctly and flushes to 0 / inf beyond, so no clamps
     return __builtin_amdgcn_ldexpf(pz, (int)(__float_as_uint(tm) - 0x4B400000u));
 }
 
@@ -174,24 +178,24 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 // Code placement of the hot loop: its speed depends on the 4-byte phase of the loop body inside the 64-byte
 // instruction-fetch lines (measured: 68.6 vs 74.5 ms per C3 frame between phases).  FT_LOOP_PHASE pins the
 // placement (64-byte boundary + FT_LOOP_PAD s_nops) so that unrelated edits cannot flip the mode.
-#ifndef FT_LOOP_PAD
-#define FT_LOOP_PAD 3
+#ifndef FT_LOOP_PAD_NEAR
+#define FT_LOOP_PAD_NEAR 15
+#endif
+#ifndef FT_LOOP_PAD_FAR
+#define FT_LOOP_PAD_FAR 2
 #endif
 
 #define FT_STR2(x) #x
 #define FT_STR(x) FT_STR2(x)
 #define FT_PHASE_ASM(pad) asm volatile(".p2align 6\n\t.rept " FT_STR(pad) "\n\ts_nop 0\n\t.endr" ::: "memory")
-#if FT_LOOP_PAD < 0
-#define FT_LOOP_PHASE() do {} while (0)
-#else
-#define FT_LOOP_PHASE() FT_PHASE_ASM(FT_LOOP_PAD)
-#endif
+#define FT_LOOP_PHASE(near) do { if (near) FT_PHASE_ASM(FT_LOOP_PAD_NEAR); else FT_PHASE_ASM(FT_LOOP_PAD_FAR); } while (0)
 
+template <bool NEAR>
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
     float si = si_;
     asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
-    FT_LOOP_PHASE();
+    FT_LOOP_PHASE(NEAR);
     for (; i + FT_UNROLL <= count; i += FT_UNROLL) {
         float4 prm[FT_UNROLL];
         float q[FT_UNROLL];
@@ -203,14 +207,20 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
             q[j] = __builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN);
         }
 #pragma unroll
-        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast(si * (ft_sqrt_fast(q[j]) - prm[j].w));
+        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast<NEAR>(si * (ft_sqrt_fast(q[j]) - prm[j].w));
     }
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
         const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
-        sum = sum + ft_exp_fast(si * (ft_sqrt_fast(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)) - prm.w));
+        sum = sum + ft_exp_fast<NEAR>(si * (ft_sqrt_fast(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)) - prm.w));
     }
     return sum;
+}
+
+// wave-uniform: are all active lanes inside the radius where every exponential of the fast runs is normal?
+__device__ __forceinline__ bool near_point_ok(f3 p, float nearR2) {
+    const float pp = p.x * p.x + p.y * p.y + p.z * p.z;               // any rounding is covered by the margin in nearR2
+    return __ballot(!(pp <= nearR2)) == 0ull;
 }
 
 // wave-uniform precondition of the fast sphere runs for this evaluation
@@ -276,6 +286,7 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
                                         const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
     cfp consts = as_const(S.consts);
     const bool fastOk = S.nStage != 0 && fast_point_ok(p);
+    const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
         float* dst = sd + in.dst * FT_BLOCK;
@@ -289,7 +300,8 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
         case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
             float sum = (in.flags & 1u) ? 0.0f : *dst;
             if (fastOk && (in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
-                sum = smooth_run_spheres_fast(ldsC + in.data, in.count, in.f0, p, sum);
+                sum = nearOk ? smooth_run_spheres_fast<true>(ldsC + in.data, in.count, in.f0, p, sum)
+                             : smooth_run_spheres_fast<false>(ldsC + in.data, in.count, in.f0, p, sum);
             } else {
                 cfp c = consts + in.data;
                 const uint32_t stride = prim_stride(in.type);
@@ -349,12 +361,14 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
     float acc = 0.0f;
     uint32_t leaf = 0;
     const bool fastOk = fast_point_ok(p);
+    const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr FT_CONST* in = as_const(S.instr) + pc;
         const uint32_t op = in->op;
         if (op == FT_OP_SMOOTH_RUN) {
             const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
-            if (__builtin_expect(fastOk, 1)) acc = smooth_run_spheres_fast(ldsC + in->data, in->count, in->f0, p, sum0);
+            if (__builtin_expect(nearOk, 1)) acc = smooth_run_spheres_fast<true>(ldsC + in->data, in->count, in->f0, p, sum0);
+            else if (fastOk) acc = smooth_run_spheres_fast<false>(ldsC + in->data, in->count, in->f0, p, sum0);
             else {                                                     // exact loop (SdfForm.fs:77-80, :129)
                 acc = sum0;
                 for (uint32_t i = 0; i < in->count; ++i) {
@@ -669,7 +683,7 @@ extern "C" __global__ void ft_math_kernel(int op, const float* __restrict__ x, c
             case 1: r = ft_log(v); break;
             case 2: r = sqrtf(v); break;
             case 4: r = ft_sqrt_fast(v); break;
-            case 5: r = ft_exp_fast(v); break;
+            case 5: r = ft_exp_fast<false>(v); break;
             default: r = v / y[i]; break;
         }
         out[i] = r;
@@ -691,7 +705,7 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
     for (unsigned long long u = (unsigned long long)lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= hi;
          u += (unsigned long long)gridDim.x * blockDim.x) {
         const float x = __uint_as_float((uint32_t)u);
-        const float a = op == 0 ? ft_sqrt_fast(x) : ft_exp_fast(x);
+        const float a = op == 0 ? ft_sqrt_fast(x) : (op == 1 ? ft_exp_fast<false>(x) : ft_exp_fast<true>(x));
         const float b = op == 0 ? sqrtf(x) : ft_exp(x);
         bad += __float_as_uint(a) != __float_as_uint(b);
     }

@@ -330,6 +330,7 @@ struct Flattener {
     FtInstr mk(uint32_t op, uint32_t dst) { FtInstr i{}; i.op = op; i.dst = dst; return i; }
 
     uint32_t stageEnd = 0;      // constant-pool prefix that must be mirrored in LDS for the fast runs
+    double nearR = 1e30;        // min over fast runs of 86/|strengthInverse| - max |centre| (conservative, in double)
     std::vector<int> matRemap;  // context-wide material handle -> dense index in this scene's table
 
     uint32_t matIndex(int handle) {
@@ -346,7 +347,7 @@ struct Flattener {
     // when t = strengthInverse * (|c - p| - r) can never exceed the range its exp shortcut is proved
     // on: finite parameters, strength > 0 and |strengthInverse| * max r <= 80.  Everything else
     // (lower bound on t, tiny or non-finite |c - p|^2) is checked per evaluation in the kernel.
-    bool fastSphereRun(const HostForm& f, size_t k, size_t run, float strengthInverse) const {
+    bool fastSphereRun(const HostForm& f, size_t k, size_t run, float strengthInverse) {
         if (b.forms[f.kids[k]].kind != HostForm::SPHERE) return false;
         if (!(f.strength > 0.0f) || !std::isfinite(strengthInverse)) return false;
         const float a = fabsf(strengthInverse);
@@ -354,12 +355,17 @@ struct Flattener {
         // |t| <= a * (65536 + r) stays below 2.9e6 (a <= 32, r <= 1e4) and t <= a * r below 88 (a * r <= 80).
         // r >= 2^-20 makes the kernel's clamp of tiny |c - p|^2 result-neutral.
         if (!(a <= 32.0f) || !(a >= 0x1p-20f)) return false;
+        double maxC = 0.0;
         for (size_t j = 0; j < run; ++j) {
             const std::vector<float>& p = b.forms[f.kids[k + j]].params;
             for (int c = 0; c < 4; ++c) if (!std::isfinite(p[c])) return false;
             for (int c = 0; c < 3; ++c) if (!(fabsf(p[c]) <= 1.0e4f)) return false;
             if (!(p[3] >= 0x1p-20f) || !(p[3] <= 1.0e4f) || !(p[3] * a <= 80.0f)) return false;
+            maxC = std::max(maxC, std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]));
         }
+        // inside this radius t = a * (r - |c - p|) >= -a * (|p| + |c|) >= -86: the exponential is a normal
+        // number and the kernel may apply 2^n by an integer add to the exponent field
+        nearR = std::min(nearR, 86.0 / (double)a - maxC - 1e-3 * (1.0 + maxC));
         return true;
     }
 
@@ -547,6 +553,7 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     if (!fl.emitObject(object, 0)) return false;
     out.nSlots = fl.maxSlot + 1;
     out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
+    out.nearR2 = (fl.stageEnd > 0 && fl.nearR > 0.0 && fl.nearR < 1e29) ? (float)(fl.nearR * fl.nearR * (1.0 - 1e-5)) : 0.0f;
     // kernel variant: 1 = the program is only staged fast sphere runs + SMOOTH_FIN + SETLEAF
     bool lean = !out.instr.empty();
     for (const FtInstr& in : out.instr) {

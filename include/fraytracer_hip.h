@@ -168,10 +168,10 @@ int ft_scene_grid_dump(const ft_scene*, int32_t g, uint32_t* cell_start, float* 
 /* math primitives of the device path, evaluated on the GPU: op 0 exp, 1 log, 2 sqrt, 3 a/b, 4 fast sqrt, 5 fast exp
  * (y = second operand, may be NULL otherwise).  Used by tests/test_math_parity.py. */
 int ft_math_eval(ft_ctx*, int32_t op, const float* x, const float* y, int64_t n, float* out);
-/* Exhaustive check, on the GPU, of the guarded fast sqrt / exp used inside the smooth-union loop
- * against the exact forms, over EVERY float of their guarded ranges; mismatches[0] = sqrt,
- * mismatches[1] = exp, both must be 0. */
-int ft_selftest_fastmath(ft_ctx*, uint64_t mismatches[2]);
+/* Exhaustive check, on the GPU, of the fast sqrt / exp forms used inside the smooth-union loop against
+ * the exact forms, over EVERY float of the ranges they are used on; mismatches[0] = sqrt,
+ * [1] = exp (ldexp form, [-2.9e6, 88]), [2] = exp (exponent-add form, [-87, 88]); all must be 0. */
+int ft_selftest_fastmath(ft_ctx*, uint64_t mismatches[3]);
 
 #ifdef __cplusplus
 }
