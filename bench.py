@@ -166,8 +166,8 @@ def main():
                          "kernel": "ft_trace_kernel_smooth_spheres", "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
-                                 "flop each although a correctly rounded sqrt / reproducible exp need 8 / 12 instructions "
-                                 "(DESIGN.md section 5: ~90 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
+                                 "flop each although a correctly rounded sqrt / reproducible exp need 5 / 11 instructions "
+                                 "(DESIGN.md section 5: ~93 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab)
