@@ -32,6 +32,7 @@ struct ft_ctx {
     bool ownStream = false;
     int numCUs = 0;
     ft::Builder builder;
+    ft::GridFiller* filler = nullptr;
     uint32_t* dCounter = nullptr;
     FtStatsDev* dStats = nullptr;
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
@@ -66,6 +67,56 @@ int ensureScratch(ft_ctx* c, size_t bytes) {
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Device-side per-cell grid build (kernels.hip ft_grid_build_kernel).  Declines (host build) for tiny grids,
+// more than FT_GRID_BUILD_MAX_ITEMS items or a scratch need above 512 MB.
+struct DeviceGridFiller : ft::GridFiller {
+    ft_ctx* c;
+    explicit DeviceGridFiller(ft_ctx* ctx) : c(ctx) {}
+    bool fill(ft::HostGrid& g, const std::vector<ft::Boundary>& bounds, float halfDiag, std::string& err) override {
+        const size_t n = bounds.size(), ncells = g.centers.size();
+        const size_t tmpBytes = ncells * n * sizeof(FtItem);
+        if (n > FT_GRID_BUILD_MAX_ITEMS || ncells * n < 100000 || tmpBytes > ((size_t)512 << 20)) return false;
+        if (hipSetDevice(c->device) != hipSuccess) return false;
+        const size_t oB = 0, oC = align256(oB + n * 16), oN = align256(oC + ncells * 12), oS = align256(oN + ncells * 4),
+                     oF = align256(oS + (ncells + 1) * 4), oT = align256(oF + 256), total = oT + tmpBytes;
+        if (ensureScratch(c, total) != FT_OK) return false;
+        unsigned char* base = static_cast<unsigned char*>(c->scratch);
+        std::vector<float> hb(n * 4);
+        for (size_t i = 0; i < n; ++i) { hb[4 * i] = bounds[i].center.x; hb[4 * i + 1] = bounds[i].center.y; hb[4 * i + 2] = bounds[i].center.z; hb[4 * i + 3] = bounds[i].radius; }
+        auto ok = [](hipError_t e) { return e == hipSuccess; };
+        if (!ok(hipMemcpyAsync(base + oB, hb.data(), n * 16, hipMemcpyHostToDevice, c->stream)) ||
+            !ok(hipMemsetAsync(base + oF, 0, 4, c->stream))) return false;
+        FtGridBuildArgs a{};
+        a.bounds = reinterpret_cast<const float*>(base + oB); a.n = (uint32_t)n; a.c = (uint32_t)g.count[0];
+        a.aabbMin[0] = g.aabbMin.x; a.aabbMin[1] = g.aabbMin.y; a.aabbMin[2] = g.aabbMin.z;
+        a.cellSize[0] = g.cellSize.x; a.cellSize[1] = g.cellSize.y; a.cellSize[2] = g.cellSize.z; a.halfDiag = halfDiag;
+        a.centers = reinterpret_cast<float*>(base + oC); a.counts = reinterpret_cast<uint32_t*>(base + oN);
+        a.tmp = reinterpret_cast<FtItem*>(base + oT); a.flags = reinterpret_cast<uint32_t*>(base + oF);
+        if (!ok(ft_launch_grid_build(&a, c->stream))) return false;
+        std::vector<uint32_t> counts(ncells);
+        uint32_t flags = 0;
+        if (!ok(hipMemcpyAsync(counts.data(), base + oN, ncells * 4, hipMemcpyDeviceToHost, c->stream)) ||
+            !ok(hipMemcpyAsync(&flags, base + oF, 4, hipMemcpyDeviceToHost, c->stream)) ||
+            !ok(hipMemcpyAsync(g.centers.data(), base + oC, ncells * 12, hipMemcpyDeviceToHost, c->stream)) ||
+            !ok(hipStreamSynchronize(c->stream))) return false;
+        if (flags & 1u) { err = "union: NaN boundary"; return false; }
+        if (flags & 2u) { err = "union: a lookup cell has no candidates (the reference would throw at Items.[0])"; return false; }
+        uint32_t total_items = 0;
+        for (size_t ci = 0; ci < ncells; ++ci) { g.cellStart[ci] = total_items; total_items += counts[ci]; }
+        g.cellStart[ncells] = total_items;
+        g.items.resize(total_items);
+        FtItem* dItems = nullptr;                                       // CSR items, exact size
+        if (!ok(hipMalloc((void**)&dItems, std::max<size_t>(16, (size_t)total_items * sizeof(FtItem))))) return false;
+        const bool done =
+            ok(hipMemcpyAsync(base + oS, g.cellStart.data(), (ncells + 1) * 4, hipMemcpyHostToDevice, c->stream)) &&
+            ok(ft_launch_grid_compact(a.tmp, reinterpret_cast<const uint32_t*>(base + oS), (uint32_t)ncells, (uint32_t)n, dItems, c->stream)) &&
+            ok(hipMemcpyAsync(g.items.data(), dItems, (size_t)total_items * sizeof(FtItem), hipMemcpyDeviceToHost, c->stream)) &&
+            ok(hipStreamSynchronize(c->stream));
+        (void)hipFree(dItems);
+        return done;
+    }
+};
 
 template <class T> size_t placed(size_t& cursor, const std::vector<T>& v) {
     const size_t at = cursor;
@@ -193,6 +244,8 @@ int ft_ctx_create(int device, ft_ctx** out) {
         if ((e = hipMalloc((void**)&c->dStats, sizeof(FtStatsDev))) != hipSuccess) { delete c; return hipFail(e, "hipMalloc"); }
         if ((e = hipMemset(c->dStats, 0, sizeof(FtStatsDev))) != hipSuccess) { delete c; return hipFail(e, "hipMemset"); }
         c->hasDevice = true;
+        c->filler = new DeviceGridFiller(c);
+        c->builder.gridFiller = c->filler;
     }
     *out = c;
     return FT_OK;
@@ -211,6 +264,7 @@ void ft_ctx_destroy(ft_ctx* c) {
         if (c->dStats) (void)hipFree(c->dStats);
         if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
     }
+    delete c->filler;
     delete c;
 }
 

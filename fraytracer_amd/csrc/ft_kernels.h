@@ -32,6 +32,19 @@ hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsByt
 hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
                                  unsigned blocks, size_t ldsBytes, hipStream_t st);
 hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st);
+// device-side buildSpatialLookup (SdfBoundary.fs:245-274): one workgroup per cell
+struct FtGridBuildArgs {
+    const float* bounds;      // n x (cx, cy, cz, r)
+    uint32_t n, c;            // items, cells per axis
+    float aabbMin[3], cellSize[3], halfDiag;
+    float* centers;           // ncells x 3
+    uint32_t* counts;         // ncells
+    FtItem* tmp;              // ncells x n, each cell's candidates sorted by (LowerBound, index)
+    uint32_t* flags;          // bit0: NaN LowerBound, bit1: empty cell
+};
+hipError_t ft_launch_grid_build(const FtGridBuildArgs* a, hipStream_t st);
+hipError_t ft_launch_grid_compact(const FtItem* tmp, const uint32_t* cellStart, uint32_t ncells, uint32_t n, FtItem* items, hipStream_t st);
+#define FT_GRID_BUILD_MAX_ITEMS 4096
 hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
 hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU);

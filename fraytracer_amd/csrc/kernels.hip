@@ -699,6 +699,78 @@ extern "C" __global__ void ft_resolve_kernel(const float* __restrict__ planes, f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-side SdfBoundary.buildSpatialLookup, per-cell part (SdfBoundary.fs:245-274).
+// One workgroup per cell: distances to all item boundaries (same float operations as the host loop),
+// upperBound = min(getMaxDistance) + |cellSize/2|, keep items with getMinDistance < upperBound, sort by
+// (LowerBound, item index) — the host's stable sort by LowerBound — with a bitonic network in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long grid_key(float lo, uint32_t idx) {
+    uint32_t u = __float_as_uint(lo);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                    // order-preserving map of float to uint
+    return ((unsigned long long)u << 32) | idx;
+}
+
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_grid_build_kernel(const FtGridBuildArgs a) {
+    __shared__ unsigned long long keys[FT_GRID_BUILD_MAX_ITEMS];
+    __shared__ float red[FT_BLOCK];
+    __shared__ uint32_t count;
+    const uint32_t tid = threadIdx.x, cell = blockIdx.x;
+    const uint32_t z = cell % a.c, y = (cell / a.c) % a.c, x = cell / (a.c * a.c);
+    const f3 cs = mk3(a.cellSize[0], a.cellSize[1], a.cellSize[2]);
+    const f3 center = mk3(a.aabbMin[0], a.aabbMin[1], a.aabbMin[2]) + cs * 0.5f + cs * mk3((float)x, (float)y, (float)z);   // :246
+    if (tid == 0) { a.centers[3 * cell] = center.x; a.centers[3 * cell + 1] = center.y; a.centers[3 * cell + 2] = center.z; count = 0; }
+    float m = INFINITY;
+    for (uint32_t i = tid; i < a.n; i += FT_BLOCK) {
+        const float* b = a.bounds + 4 * i;
+        const float v = ft_distance(mk3(b[0], b[1], b[2]), center) + b[3];          // getMaxDistance (:251)
+        if (v < m) m = v;
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (uint32_t s = FT_BLOCK / 2; s > 0; s >>= 1) { if (tid < s && red[tid + s] < red[tid]) red[tid] = red[tid + s]; __syncthreads(); }
+    const float upperBound = red[0] + a.halfDiag;                                    // :253
+    bool nan = false;
+    for (uint32_t i = tid; i < a.n; i += FT_BLOCK) {
+        const float* b = a.bounds + 4 * i;
+        const float lo = ft_distance(mk3(b[0], b[1], b[2]), center) - b[3];         // getMinDistance (:257)
+        nan |= lo != lo;
+        if (lo < upperBound) keys[atomicAdd(&count, 1u)] = grid_key(lo, i);          // order fixed by the sort below
+    }
+    if (nan) atomicOr(a.flags, 1u);
+    __syncthreads();
+    const uint32_t cnt = count;
+    if (cnt == 0) { if (tid == 0) { atomicOr(a.flags, 2u); a.counts[cell] = 0; } return; }
+    uint32_t pow2 = 1; while (pow2 < cnt) pow2 <<= 1;
+    for (uint32_t i = cnt + tid; i < pow2; i += FT_BLOCK) keys[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= pow2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < pow2; i += FT_BLOCK) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long p = keys[i], q = keys[l];
+                    if (((i & k) == 0) ? (p > q) : (p < q)) { keys[i] = q; keys[l] = p; }
+                }
+            }
+            __syncthreads();
+        }
+    FtItem* out = a.tmp + (size_t)cell * a.n;
+    for (uint32_t i = tid; i < cnt; i += FT_BLOCK) {
+        const unsigned long long kx = keys[i];
+        uint32_t u = (uint32_t)(kx >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        out[i].lowerBound = __uint_as_float(u);
+        out[i].child = (uint32_t)kx;
+    }
+    if (tid == 0) a.counts[cell] = cnt;
+}
+
+extern "C" __global__ void ft_grid_compact_kernel(const FtItem* __restrict__ tmp, const uint32_t* __restrict__ cellStart, uint32_t n, FtItem* __restrict__ items) {
+    const uint32_t cell = blockIdx.x, beg = cellStart[cell], cnt = cellStart[cell + 1] - beg;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) items[beg + i] = tmp[(size_t)cell * n + i];
+}
+
 // exhaustive proof of the fast forms: every float bit pattern in [lo, hi] (same sign), fast vs exact
 extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, unsigned long long* mismatches) {
     unsigned long long bad = 0;
@@ -730,6 +802,14 @@ extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pt
 }
 extern "C" hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(ft_math_kernel, dim3(1024), dim3(256), 0, st, op, x, y, n, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_launch_grid_build(const FtGridBuildArgs* a, hipStream_t st) {
+    hipLaunchKernelGGL(ft_grid_build_kernel, dim3(a->c * a->c * a->c), dim3(FT_BLOCK), 0, st, *a);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_launch_grid_compact(const FtItem* tmp, const uint32_t* cellStart, uint32_t ncells, uint32_t n, FtItem* items, hipStream_t st) {
+    hipLaunchKernelGGL(ft_grid_compact_kernel, dim3(ncells), dim3(128), 0, st, tmp, cellStart, n, items);
     return hipGetLastError();
 }
 extern "C" hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st) {

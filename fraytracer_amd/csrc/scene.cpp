@@ -46,7 +46,7 @@ static inline float maxDistance(const Boundary& x, f3 p) { return ft_distance(x.
 // SdfBoundary.buildSpatialLookup (SdfBoundary.fs:225-274).  Quirks kept: all three counts are
 // derived from aabbSize.X (:237-239); upperBound adds half a cell diagonal once (:253).
 // ------------------------------------------------------------------------------------------------
-std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds, std::string& err) {
+std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds, std::string& err, GridFiller* filler) {
     auto g = std::make_shared<HostGrid>();
     const size_t n = bounds.size();
     f3 aabbMin = bounds[0].center - splat3(bounds[0].radius);
@@ -70,6 +70,12 @@ std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds
     g->centers.resize(ncells);
     g->cellStart.assign(ncells + 1, 0);
     const float halfDiag = ft_length(g->cellSize * 0.5f);
+    if (filler) {                                                       // device-side per-cell build (same arithmetic)
+        std::string ferr;
+        if (filler->fill(*g, bounds, halfDiag, ferr)) return g;
+        if (!ferr.empty()) { err = ferr; return nullptr; }              // a real error (NaN boundary, empty cell), not a decline
+        g->centers.assign(ncells, mk3(0, 0, 0)); g->cellStart.assign(ncells + 1, 0); g->items.clear();
+    }
 
     // one x-slab of cells per task (the reference parallelises the same build over y, Array3D.fs:4-14);
     // Distance(center_i, cellCenter) is computed once and reused for getMaxDistance / getMinDistance —
@@ -201,7 +207,7 @@ int Builder::formUnion(const int* kids, int n) {                       // SdfFor
     if (n == 1) return kids[0];
     HostForm f; f.kind = HostForm::UNION; f.kids.assign(kids, kids + n);
     std::vector<Boundary> bs; for (int i = 0; i < n; ++i) bs.push_back(forms[kids[i]].boundary);
-    f.grid = buildSpatialLookup(bs, err);
+    f.grid = buildSpatialLookup(bs, err, gridFiller);
     if (!f.grid) return FT_ERR_UNSUPPORTED_;
     Boundary acc = bs[0];                                              // Seq.reduce union (:36-39)
     for (int i = 1; i < n; ++i) acc = boundaryUnion(acc, bs[i]);

@@ -44,12 +44,21 @@ struct HostObject {                                           // reified SdfObje
 
 struct HostLight { FtLight dev; };
 
+// Optional accelerator for the per-cell part of buildSpatialLookup: given the grid frame
+// (aabbMin, cellSize, count) and the item boundaries it must fill centers / cellStart / items exactly as the
+// host loop does; returns false (leaving g untouched) if it declines (no GPU, too many items, ...).
+struct GridFiller {
+    virtual ~GridFiller() {}
+    virtual bool fill(HostGrid& g, const std::vector<Boundary>& bounds, float halfDiag, std::string& err) = 0;
+};
+
 struct Builder {                                              // one per ft_ctx
     std::vector<HostForm> forms;
     std::vector<HostObject> objects;
     std::vector<f3> materials;
     std::vector<HostLight> lights;
     std::string err;
+    GridFiller* gridFiller = nullptr;                         // owned by the context; null = host build
 
     int sphere(f3 c, float r);
     int capsule(f3 from, f3 to, float r);
@@ -92,7 +101,7 @@ struct FlatScene {                                            // host copy of ev
 // Boundary algebra (SdfBoundary.fs:7-67) and grid build (SdfBoundary.fs:225-274)
 Boundary boundaryUnion(Boundary a, Boundary b);
 Boundary boundaryIntersection(Boundary a, Boundary b);
-std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds, std::string& err);
+std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds, std::string& err, GridFiller* filler = nullptr);
 
 // flatten the tree under `object` (+ lights, background) into the device layout; false + err on failure
 bool flatten(const Builder& b, int object, const float bg[3], const int* lights, int nLights, FlatScene& out, std::string& err);

@@ -305,3 +305,21 @@ def test_config3_full_frame_properties_and_sampled_oracle(gpu, oracle):
         ref = full.reshape(W // (R * S), R, S, H, 3)[:, r]
         assert_bit_equal(got, ref, f"stripe rank {r}")
     assert shadow == st["rays_shadow"]
+
+
+def test_device_grid_build_equals_host_build(gpu, oracle):
+    """the per-cell part of buildSpatialLookup runs on the GPU for large unions; the resulting
+    grid (cell centres, CSR offsets, sorted (LowerBound, item) lists) must equal the host build and the
+    oracle's bit for bit."""
+    host = ft.Device(-1)
+    try:
+        for scene in (syn.console_like(n=1000)[0], syn.console_like(seed=4, n=400, factory=syn.random_triangle)[0]):
+            gd = gpu.scene(scene).grid(0)
+            gh = host.scene(scene).grid(0)
+            assert gd["counts"] == gh["counts"]
+            for k in ("aabbMin", "cellSizeInv", "centers", "lower"):
+                assert np.array_equal(gd[k].view(np.uint32), gh[k].view(np.uint32)), k
+            assert np.array_equal(gd["cell_start"], gh["cell_start"]) and np.array_equal(gd["child"], gh["child"])
+            assert len(gd["child"]) > 20000
+    finally:
+        host.close()
