@@ -145,7 +145,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d = FtSceneDev{};
     d.nInstr = (uint32_t)f.instr.size(); d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
-    d.nStage = f.nStage; d.nearR2 = f.nearR2;
+    d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));

@@ -95,7 +95,8 @@ struct FtSceneDev {             // passed by value as kernel argument
     float bg[3];
     uint32_t nStage;            // leading floats of consts[] that every workgroup stages into LDS
     float nearR2;               // |p|^2 <= nearR2  =>  every t of the fast sphere runs is >= -87 (exp result normal)
-    uint32_t pad0, pad1, pad2;
+    uint32_t fastQ;             // 1: every union candidate admits the clamped fast sqrt (scene.cpp: unionFastQ)
+    uint32_t pad1, pad2;
 };
 
 struct FtStatsDev {

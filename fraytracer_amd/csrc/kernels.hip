@@ -52,29 +52,50 @@ __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
     r.color[0] = q->color[0]; r.color[1] = q->color[1]; r.color[2] = q->color[2]; r.pad = 0.0f; return r;
 }
 
-__device__ __forceinline__ float prim_sphere(cfp c, f3 p) {
-    return ft_distance(ld3(c), p) - c[3];                              // SdfForm.fs:129
+// ---- square roots -----------------------------------------------------------------------------------------
+// ft_sqrt_fast: bit-identical to sqrtf for every float in [2^-96, 2^100] (proved by exhaustion,
+// ft_selftest_fastmath).  ft_sq<FQ>: FQ = false is the IEEE sqrtf.  FQ = true is used only where the
+// caller has established (a) the operand is finite and < 2^100 (p finite, |p|inf < 20000, all scene
+// coordinates <= 1e4: fast_point_ok + flatten-time checks) and (b) the root is next reduced by a radius
+// >= 2^-20: then clamping the operand at 2^-96 cannot change the difference (both sqrt(q) and 2^-48 are
+// far below half an ulp of the radius), so the 6-instruction clamped form gives the reference's value.
+#define FT_FAST_Q_MIN 0x1p-96f
+__device__ __forceinline__ float ft_sqrt_fast(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);      // v_rsq_f32
+    const float s = x * r;                          // ~1 ulp estimate of sqrt(x)
+    const float h = 0.5f * r;                       // ~1/(2 sqrt(x))
+    const float d = fmaf(-s, s, x);                 // residual x - s^2 (one rounding)
+    return fmaf(d, h, s);                           // s + d/(2 sqrt(x)): correctly rounded on the whole proved range
 }
 
-__device__ __forceinline__ float prim_capsule(cfp c, f3 p) {
+template <bool FQ> __device__ __forceinline__ float ft_sq(float q) {
+    return FQ ? ft_sqrt_fast(__builtin_fmaxf(q, FT_FAST_Q_MIN)) : sqrtf(q);
+}
+template <bool FQ> __device__ __forceinline__ float ft_dist(f3 a, f3 b) { const f3 d = a - b; return ft_sq<FQ>(ft_dot(d, d)); }
+
+template <bool FQ> __device__ __forceinline__ float prim_sphere(cfp c, f3 p) {
+    return ft_dist<FQ>(ld3(c), p) - c[3];                              // SdfForm.fs:129
+}
+
+template <bool FQ> __device__ __forceinline__ float prim_capsule(cfp c, f3 p) {
     const f3 diff = p - ld3(c);                                        // :153
     const f3 dir = ld3(c + 4);
     const float t = ft_dot(diff, ld3(c + 8));                          // :154
     f3 w = dir * t;                                                    // :160
     if (t >= 1.0f) w = dir;                                            // :157-158
     if (t <= 0.0f) w = mk3(0.0f, 0.0f, 0.0f);                          // :155-156  (diff - 0 == diff)
-    return ft_distance(diff, w) - c[3];                                // :164
+    return ft_dist<FQ>(diff, w) - c[3];                                // :164
 }
 
-__device__ __forceinline__ float prim_torus(cfp c, f3 p) {
+template <bool FQ> __device__ __forceinline__ float prim_torus(cfp c, f3 p) {
     const f3 n = ld3(c + 4);
     const float distanceToPlane = ft_dot(p, n) + c[8];                 // :190
-    const float distanceToCenter = ft_distance(ld3(c), p - (distanceToPlane * n));   // :191
+    const float distanceToCenter = ft_dist<FQ>(ld3(c), p - (distanceToPlane * n));   // :191
     const float distanceToCircle = distanceToCenter - c[3];            // :192
-    return sqrtf(distanceToPlane * distanceToPlane + distanceToCircle * distanceToCircle) - c[7];   // :194
+    return ft_sq<FQ>(distanceToPlane * distanceToPlane + distanceToCircle * distanceToCircle) - c[7];   // :194
 }
 
-__device__ __forceinline__ float prim_triangle(cfp c, f3 p) {
+template <bool FQ> __device__ __forceinline__ float prim_triangle(cfp c, f3 p) {
     const f3 p1 = p - ld3(c), p2 = p - ld3(c + 4), p3 = p - ld3(c + 8);   // :228-230
     float distance;
     const int s = ft_sign_i(ft_dot(ld3(c + 40), p1)) + ft_sign_i(ft_dot(ld3(c + 44), p2)) + ft_sign_i(ft_dot(ld3(c + 48), p3));
@@ -83,29 +104,30 @@ __device__ __forceinline__ float prim_triangle(cfp c, f3 p) {
         const float d21 = ft_distance2(p1, v21 * ft_clamp01(ft_dot(ld3(c + 24), p1)));   // :240
         const float d32 = ft_distance2(p2, v32 * ft_clamp01(ft_dot(ld3(c + 28), p2)));   // :241
         const float d13 = ft_distance2(p3, v13 * ft_clamp01(ft_dot(ld3(c + 32), p3)));   // :242
-        distance = sqrtf(ft_min(d13, ft_min(d32, d21)));               // :243-244
+        distance = ft_sq<FQ>(ft_min(d13, ft_min(d32, d21)));           // :243-244
     } else {
         distance = fabsf(ft_dot(ld3(c + 36), p1));                     // :247-248
     }
     return distance - c[3];                                            // :250
 }
 
-__device__ __forceinline__ float prim_box(cfp c, f3 p) {   // EXTENSION
+__device__ __forceinline__ float prim_box(cfp c, f3 p) {   // EXTENSION (always the IEEE sqrt: its root is not reduced by a radius)
     const f3 d = p - ld3(c);
     const f3 q = mk3(fabsf(d.x) - c[4], fabsf(d.y) - c[5], fabsf(d.z) - c[6]);
     const f3 qp = mk3(ft_max(q.x, 0.0f), ft_max(q.y, 0.0f), ft_max(q.z, 0.0f));
     return ft_length(qp) + ft_min(ft_max(q.x, ft_max(q.y, q.z)), 0.0f);
 }
 
-__device__ __forceinline__ float prim_eval(uint32_t type, cfp c, f3 p) {
+template <bool FQ> __device__ __forceinline__ float prim_eval_t(uint32_t type, cfp c, f3 p) {
     switch (type) {
-        case FT_PR_SPHERE: return prim_sphere(c, p);
-        case FT_PR_CAPSULE: return prim_capsule(c, p);
-        case FT_PR_TORUS: return prim_torus(c, p);
-        case FT_PR_TRIANGLE: return prim_triangle(c, p);
+        case FT_PR_SPHERE: return prim_sphere<FQ>(c, p);
+        case FT_PR_CAPSULE: return prim_capsule<FQ>(c, p);
+        case FT_PR_TORUS: return prim_torus<FQ>(c, p);
+        case FT_PR_TRIANGLE: return prim_triangle<FQ>(c, p);
         default: return prim_box(c, p);
     }
 }
+__device__ __forceinline__ float prim_eval(uint32_t type, cfp c, f3 p) { return prim_eval_t<false>(type, c, p); }
 
 __device__ __forceinline__ uint32_t prim_stride(uint32_t type) {
     switch (type) {
@@ -128,14 +150,6 @@ __device__ __forceinline__ uint32_t prim_stride(uint32_t type) {
 //   ft_exp_fast:  t in [-2.9e6, 88]: no NaN test and no clamps; n is taken from the mantissa of the
 //                 magic-number sum (one integer subtract) instead of v_rndne + v_cvt (both half rate).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ft_sqrt_fast(float x) {
-    const float r = __builtin_amdgcn_rsqf(x);      // v_rsq_f32
-    const float s = x * r;                          // ~1 ulp estimate of sqrt(x)
-    const float h = 0.5f * r;                       // ~1/(2 sqrt(x))
-    const float d = fmaf(-s, s, x);                 // residual x - s^2 (one rounding)
-    return fmaf(d, h, s);                           // s + d/(2 sqrt(x)): correctly rounded on the whole proved range
-}
-
 template <bool NEAR>
 __device__ __forceinline__ float ft_exp_fast(float x) {
     const float tm = fmaf(x, 0x1.715476p+0f, 12582912.0f);
@@ -156,7 +170,6 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
     return __builtin_amdgcn_ldexpf(pz, (int)(__float_as_uint(tm) - 0x4B400000u));
 }
 
-#define FT_FAST_Q_MIN 0x1p-96f
 #define FT_FAST_P_MAX 20000.0f             // |p|inf bound under which every |c - p|^2 < 2^32 (|c|inf <= 10000, scene.cpp)
 #define FT_FAST_T_LO (-2900000.0f)         // |t * log2e| < 2^22: the magic-number rounding stays exact
 #define FT_FAST_T_HI 88.0f
@@ -235,6 +248,7 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 // argmin of SdfObject.fs:27-46 tracked in the same sweep (same grid, same tests, strict '<').
 // Per-lane candidate list; lanes of a wave are neighbouring pixels and mostly share the cell.
 // ------------------------------------------------------------------------------------------------
+template <bool FQ>
 __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            const float* __restrict__ sd, const uint32_t* __restrict__ sl,
                                            float& outD, uint32_t& outLeaf) {
@@ -256,7 +270,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
         const ItemRegs rec = ld_item(items + i);
         const uint32_t type = rec.b.y & 15u, data = rec.b.y >> 4;
         if (type == FT_PR_SLOT) { mn = sd[data * FT_BLOCK]; leaf = sl[data * FT_BLOCK]; }
-        else { mn = prim_eval(type, consts + data, p); leaf = rec.b.z; }
+        else { mn = prim_eval_t<FQ>(type, consts + data, p); leaf = rec.b.z; }
     }
     // The reference scans the whole list (SdfForm.fs:27).  The list is sorted by LowerBound
     // (SdfBoundary.fs:267-268; verified NaN-free when the grid is built) and `mn` never grows, so once
@@ -265,11 +279,11 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
     for (++i; i < end; ++i) {
         const ItemRegs cur = ld_item(items + i);
         if (!(mn > cur.a.x - distanceToCenter)) break;                 // :30 false for this and all later candidates
-        if (mn > ft_distance(mk3(cur.a.y, cur.a.z, cur.a.w), p) - __uint_as_float(cur.b.x)) {   // :31 getMinDistance
+        if (mn > ft_dist<FQ>(mk3(cur.a.y, cur.a.z, cur.a.w), p) - __uint_as_float(cur.b.x)) {   // :31 getMinDistance
             const uint32_t type = cur.b.y & 15u, data = cur.b.y >> 4;
             float d; uint32_t l;
             if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
-            else { d = prim_eval(type, consts + data, p); l = cur.b.z; }
+            else { d = prim_eval_t<FQ>(type, consts + data, p); l = cur.b.z; }
             if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
             mn = ft_min(mn, d);                                        // SdfForm.fs:33
         }
@@ -285,8 +299,8 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
                                         const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
     cfp consts = as_const(S.consts);
-    const bool fastOk = S.nStage != 0 && fast_point_ok(p);
-    const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
+    const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
+    const bool nearOk = fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
         float* dst = sd + in.dst * FT_BLOCK;
@@ -299,7 +313,7 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
             break;
         case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
             float sum = (in.flags & 1u) ? 0.0f : *dst;
-            if (fastOk && (in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
+            if (fastOk && S.nStage != 0 && (in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
                 sum = nearOk ? smooth_run_spheres_fast<true>(ldsC + in.data, in.count, in.f0, p, sum)
                              : smooth_run_spheres_fast<false>(ldsC + in.data, in.count, in.f0, p, sum);
             } else {
@@ -342,7 +356,8 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
         }
         case FT_OP_UNION: {
             float d; uint32_t l;
-            eval_union(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
+            if (fastOk && S.fastQ) eval_union<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
+            else eval_union<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
             *dst = d; sl[in.dst * FT_BLOCK] = l;
             break;
         }

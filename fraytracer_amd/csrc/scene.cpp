@@ -335,6 +335,8 @@ struct Flattener {
     }
     FtInstr mk(uint32_t op, uint32_t dst) { FtInstr i{}; i.op = op; i.dst = dst; return i; }
 
+    bool unionFastQ = true;     // all union candidates so far admit the kernel's clamped fast sqrt (see noteUnionChild)
+    bool anyUnion = false;
     uint32_t stageEnd = 0;      // constant-pool prefix that must be mirrored in LDS for the fast runs
     double nearR = 1e30;        // min over fast runs of 86/|strengthInverse| - max |centre| (conservative, in double)
     std::vector<int> matRemap;  // context-wide material handle -> dense index in this scene's table
@@ -464,6 +466,26 @@ struct Flattener {
         return true;
     }
 
+    // The union loop's fast square roots (kernels.hip ft_sq<true>) need: finite coordinates of magnitude
+    // <= 1e4 (operands stay far below 2^100 once |p|inf < 20000) and every radius that is subtracted from
+    // a root >= 2^-20 (so clamping a root at 2^-48 cannot change the difference): the candidate's bounding
+    // radius (getMinDistance), sphere / capsule / triangle radius, torus major and minor radius.
+    void noteUnionChild(const HostForm& kf) {
+        auto okc = [](float v) { return std::isfinite(v) && fabsf(v) <= 1.0e4f; };
+        auto okr = [](float v) { return std::isfinite(v) && v >= 0x1p-20f && v <= 1.0e4f; };
+        bool ok = okc(kf.boundary.center.x) && okc(kf.boundary.center.y) && okc(kf.boundary.center.z) && okr(kf.boundary.radius);
+        if (kf.isPrim()) {
+            const std::vector<float>& p = kf.params;
+            for (float v : p) ok = ok && okc(v);
+            switch (kf.kind) {
+                case HostForm::SPHERE: case HostForm::CAPSULE: case HostForm::TRIANGLE: ok = ok && okr(p[3]); break;
+                case HostForm::TORUS: ok = ok && okr(p[3]) && okr(p[7]); break;
+                default: break;                                         // box keeps the IEEE sqrt
+            }
+        }
+        unionFastQ = unionFastQ && ok;
+    }
+
     // union over f.kids; objs[i] >= 0 when child i is an SdfObject (material tracking), else -1.
     // Primitive children go straight into the child table; any other child is evaluated first,
     // unconditionally, into its own slot (evaluation has no side effects, so applying the
@@ -474,6 +496,7 @@ struct Flattener {
         uint32_t nextSlot = dst + 1;
         for (size_t k = 0; k < f.kids.size(); ++k) {
             const HostForm& kf = b.forms[f.kids[k]];
+            noteUnionChild(kf); anyUnion = true;
             FtChild c{};
             c.bc[0] = kf.boundary.center.x; c.bc[1] = kf.boundary.center.y; c.bc[2] = kf.boundary.center.z; c.br = kf.boundary.radius;
             const int ko = objs[k];
@@ -560,6 +583,7 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     out.nSlots = fl.maxSlot + 1;
     out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
     out.nearR2 = (fl.stageEnd > 0 && fl.nearR > 0.0 && fl.nearR < 1e29) ? (float)(fl.nearR * fl.nearR * (1.0 - 1e-5)) : 0.0f;
+    out.fastQ = (fl.anyUnion && fl.unionFastQ) ? 1u : 0u;
     // kernel variant: 1 = the program is only staged fast sphere runs + SMOOTH_FIN + SETLEAF
     bool lean = !out.instr.empty();
     for (const FtInstr& in : out.instr) {

@@ -94,6 +94,7 @@ struct FlatScene {                                            // host copy of ev
     uint32_t nSlots = 1;
     uint32_t nStage = 0;                                      // consts[0, nStage) is mirrored in LDS by every workgroup
     float nearR2 = 0.0f;                                      // see FtSceneDev::nearR2
+    uint32_t fastQ = 0;                                       // see FtSceneDev::fastQ
     uint32_t fastPath = 0;
     float bg[3] = {0, 0, 0};
 };

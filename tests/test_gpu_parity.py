@@ -323,3 +323,33 @@ def test_device_grid_build_equals_host_build(gpu, oracle):
             assert len(gd["child"]) > 20000
     finally:
         host.close()
+
+
+def test_union_fast_sqrt_clamp_points(gpu, oracle):
+    """The union loop's clamped fast square roots (flatten-time flag fastQ + per-evaluation point test) must
+    give the reference's value also where a root's operand is zero or tiny: exactly on sphere / torus centres,
+    capsule end points and axis points, triangle vertices and edges; and must fall back to the IEEE path for
+    huge / non-finite points."""
+    rng = np.random.default_rng(11)
+    for factory in (syn.random_sphere, syn.random_capsule, syn.random_torus, syn.random_triangle):
+        scene, _ = syn.console_like(seed=6, n=80, factory=factory)
+        ds, os_ = both(gpu, oracle, scene)
+        assert ds.info()["n_grids"] == 1
+        union = scene.Object.kids[0].kids[0]
+        special = []
+        for obj in union.kids:
+            form = obj.kids[1]
+            for a in form.args:
+                if isinstance(a, tuple):
+                    special.append(a)
+            if form.kind == "capsule":
+                special.append(tuple(0.5 * (np.float32(form.args[0][i]) + np.float32(form.args[1][i])) for i in range(3)))
+            if form.kind == "triangle":
+                special.append(tuple(0.5 * (np.float32(form.args[0][i]) + np.float32(form.args[2][i])) for i in range(3)))
+        special = np.array(special, np.float32)
+        pts = np.concatenate([special, special + np.float32(1e-20), special + np.float32(3e-13), rng.uniform(-5, 5, (3000, 3)),
+                              [[3e4, 0, 0], [1e30, 1e30, 0], [np.inf, 0, 0], [np.nan, 1, 2]]]).astype(np.float32)
+        d, _ = ds.eval_distance(pts)
+        O = oracle.Oracle()
+        with np.errstate(all="ignore"):
+            assert_bit_equal(d, O.form_distance(O.object_form(os_.object), pts), f"union fast-sqrt, {factory.__name__}")
