@@ -51,8 +51,12 @@ def pmc_traffic_bytes():
         txt = open(f).read()
         fe, wr = re.search(r"FETCH_SIZE\s+([0-9.e+]+)", txt), re.search(r"WRITE_SIZE\s+([0-9.e+]+)", txt)
         if fe and wr and "smooth_spheres" in txt:
-            return int((2.0 * float(fe.group(1)) + float(wr.group(1))) * 1024), os.path.basename(f)
-    return None, None
+            busy = None
+            av, ga = re.search(r"SQ_ACTIVE_INST_VALU\s+([0-9.e+]+)", txt), re.search(r"GRBM_GUI_ACTIVE\s+([0-9.e+]+)", txt)
+            if av and ga:   # one count per VALU instruction, 2 issue cycles each on gfx950; GRBM_GUI_ACTIVE sums 8 XCDs
+                busy = round(float(av.group(1)) * 2.0 / (1024.0 * float(ga.group(1)) / 8.0), 3)
+            return int((2.0 * float(fe.group(1)) + float(wr.group(1))) * 1024), os.path.basename(f), busy
+    return None, None, None
 
 
 def main():
@@ -145,7 +149,7 @@ def main():
         mrays = rays / dt / 1e6
         # roofline of the dominant (only) kernel, from this rank's launches: algorithmic lane-ops per
         # launch / mean HIP-event duration of a launch
-        traffic, traffic_src = pmc_traffic_bytes() if (W == 4096 and world == 1) else (None, None)
+        traffic, traffic_src, valu_busy = pmc_traffic_bytes() if (W == 4096 and world == 1) else (None, None, None)
         flops_launch = algorithmic_flops(st, args.spheres) / args.steps
         launch_s = st["kernel_ms"] / 1e3 / args.steps
         achieved = flops_launch / launch_s / 1e12
@@ -163,6 +167,7 @@ def main():
                        "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "valu_busy_pmc": valu_busy,
                          "kernel": "ft_trace_kernel_smooth_spheres", "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
