@@ -95,7 +95,11 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
     std::lock_guard<std::mutex> lock(g_mu);
     std::vector<ncclComm_t> comms;
     std::string err;
-    if (n > 1 && !getComms(devs, comms, err)) return fail(FT_ERR_COMM, err);
+    // several contexts on ONE device (rehearsal on a single-GPU machine; RCCL refuses duplicate GPUs): the
+    // slabs are collected with device-to-device copies instead of the gather; everything else is the same path
+    bool sameDevice = n > 1;
+    for (int r = 1; r < n; ++r) sameDevice = sameDevice && devs[r] == devs[0];
+    if (n > 1 && !sameDevice && !getComms(devs, comms, err)) return fail(FT_ERR_COMM, err);
 
     std::vector<float*> send(n, nullptr);
     float* recv = nullptr;
@@ -122,7 +126,10 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
         ft_render_params p = *full;
         p.x0 = 0; p.n_columns = cols; p.stripe_width = S; p.stripe_ranks = n; p.stripe_rank = r;
         int rc = ft_render_device(ctxs[r], scenes[r], cam, &p, send[r]);
-        if (rc == FT_OK && n > 1) {
+        if (rc == FT_OK && n > 1 && sameDevice) {
+            if (hipMemcpyAsync(recv + (size_t)r * slab, send[r], slab * sizeof(float), hipMemcpyDeviceToDevice,
+                               (hipStream_t)ft_ctx_stream_(ctxs[r])) != hipSuccess) { rc = FT_ERR_HIP; errs[r] = "device-to-device slab copy failed"; }
+        } else if (rc == FT_OK && n > 1) {
             ncclResult_t nr = g_rccl.Gather(send[r], recv, slab, ncclFloat, 0, comms[r], (hipStream_t)ft_ctx_stream_(ctxs[r]));
             if (nr != ncclSuccess) { rc = FT_ERR_COMM; errs[r] = std::string("ncclGather: ") + g_rccl.GetErrorString(nr); }
         } else if (rc != FT_OK) errs[r] = ft_last_error();

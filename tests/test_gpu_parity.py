@@ -208,6 +208,17 @@ def test_render_multi_single_process_path(gpu):
     img, st1 = ft.render_multi([gpu], scene, EPS, LEN, ft.ImageSize(W, H), cam, stripe_width=16)
     assert_bit_equal(img, full, "ft_render_multi n=1")
     assert st1["rays_primary"] == st["rays_primary"] and st1["rays_shadow"] == st["rays_shadow"]
+    # n = 2 and 4 contexts on the one GPU: thread-per-context, interleaved stripes, slab collection and
+    # de-interleaving all run (the collection itself degenerates to device copies: RCCL refuses duplicate GPUs)
+    extra = [ft.Device(0) for _ in range(3)]
+    try:
+        for devs in ([gpu, extra[0]], [gpu] + extra):
+            imgn, stn = ft.render_multi(devs, scene, EPS, LEN, ft.ImageSize(W, H), cam, stripe_width=8)
+            assert_bit_equal(imgn, full, f"ft_render_multi n={len(devs)} on one device")
+            assert stn["rays_primary"] == st["rays_primary"] and stn["rays_shadow"] == st["rays_shadow"]
+    finally:
+        for d in extra:
+            d.close()
     other = ft.Device(0)
     try:
         p = ft.api.C.c_void_p()
