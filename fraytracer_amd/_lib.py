@@ -59,7 +59,8 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("x0", C.c_int32), ("n_columns", C.c_int32),
                 ("stripe_width", C.c_int32), ("stripe_ranks", C.c_int32), ("stripe_rank", C.c_int32),
                 ("spp", C.c_int32), ("epsilon", C.c_float), ("length", C.c_float),
-                ("ao_samples", C.c_int32), ("ao_radius", C.c_float)]
+                ("ao_samples", C.c_int32), ("ao_radius", C.c_float),
+                ("max_bounces", C.c_int32), ("spectral", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -97,6 +98,8 @@ SYMBOLS = {
     "ft_form_union_smooth": (_H, [_P, C.c_float, C.POINTER(_H), C.c_int32]),
     "ft_form_boundary": (C.c_int, [_P, _H, C.POINTER(Boundary)]),
     "ft_material_solid": (_H, [_P, _F3]),
+    "ft_material_glass": (_H, [_P, _F3, C.c_float, C.c_float]),
+    "ft_spectral_table": (C.c_int, [C.c_int32, C.c_void_p]),
     "ft_object_create": (_H, [_P, _H, _H]),
     "ft_object_union": (_H, [_P, C.POINTER(_H), C.c_int32]),
     "ft_object_subtract": (_H, [_P, _H, _H]),

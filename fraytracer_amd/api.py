@@ -128,6 +128,11 @@ class SdfMaterial:
     def createSolid(color):
         return Material("solid", (_v3(color),))
 
+    @staticmethod
+    def createGlass(tint, ior, dispersion=0.0):
+        """EXTENSION (not in the reference): refracting material, Cauchy dispersion in um^2."""
+        return Material("glass", (_v3(tint), float(np.float32(ior)), float(np.float32(dispersion))))
+
 
 class SdfObject:
     @staticmethod
@@ -196,7 +201,7 @@ def realise(node, backend, memo=None):
         elif k == "unionSmooth": h = backend.form_union_smooth(node.args[0], kids)
         else: raise ValueError(k)
     elif isinstance(node, Material):
-        h = backend.material_solid(node.args[0])
+        h = backend.material_solid(node.args[0]) if k == "solid" else backend.material_glass(*node.args)
     elif isinstance(node, Object):
         if k == "create": h = backend.object_create(kids[0], kids[1])
         elif k == "union": h = backend.object_union(kids)
@@ -273,6 +278,7 @@ class Device:
     def form_intersect(self, hs): return check(lib.ft_form_intersect(self._ctx, *_handles(hs)))
     def form_union_smooth(self, k, hs): return check(lib.ft_form_union_smooth(self._ctx, k, *_handles(hs)))
     def material_solid(self, rgb): return check(lib.ft_material_solid(self._ctx, _f3(rgb)))
+    def material_glass(self, tint, ior, dispersion): return check(lib.ft_material_glass(self._ctx, _f3(tint), ior, dispersion))
     def object_create(self, m, f): return check(lib.ft_object_create(self._ctx, m, f))
     def object_union(self, hs): return check(lib.ft_object_union(self._ctx, *_handles(hs)))
     def object_subtract(self, o, f): return check(lib.ft_object_subtract(self._ctx, o, f))
@@ -350,15 +356,17 @@ class DeviceScene:
                 "counts": tuple(counts), "cell_start": cell_start, "centers": centers, "lower": lower, "child": child}
 
     def _params(self, imageSize, epsilon, length, x0=0, n_columns=None, stripe_width=None, stripe_ranks=1, stripe_rank=0,
-                spp=1, ao_samples=0, ao_radius=0.0):
-        """spp / ao_samples / ao_radius are EXTENSIONS (not in the reference); defaults = the reference."""
+                spp=1, ao_samples=0, ao_radius=0.0, max_bounces=0, spectral=0):
+        """spp / ao_samples / ao_radius / max_bounces / spectral are EXTENSIONS (not in the reference);
+        defaults = the reference."""
         W, H = int(imageSize.X), int(imageSize.Y)
         if n_columns is None:
             n_columns = W - x0 if stripe_ranks == 1 else W // stripe_ranks
         if stripe_width is None:
             stripe_width = n_columns
         return _lib.RenderParams(W, H, int(x0), int(n_columns), int(stripe_width), int(stripe_ranks), int(stripe_rank),
-                                 int(spp), float(epsilon), float(length), int(ao_samples), float(ao_radius))
+                                 int(spp), float(epsilon), float(length), int(ao_samples), float(ao_radius),
+                                 int(max_bounces), int(spectral))
 
     def render(self, epsilon, length, imageSize, camera, **tiling):
         """Image.render (Image.fs:26-35) -> (FColor[X,Y] as float32 [n_columns, Y, 3], stats dict)."""
@@ -397,6 +405,13 @@ class DeviceScene:
         return d, m
 
 
+def spectral_table(nw):
+    """EXTENSION: the library's wavelength table, float32 [nw, 4] = rgb weight, Cauchy term (ft_spectral_table)."""
+    out = np.empty((int(nw), 4), np.float32)
+    check(lib.ft_spectral_table(int(nw), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def render_multi(devices, scene, epsilon, length, imageSize, camera, stripe_width=16):
     """ft_render_multi: single-process multi-GPU render (one host thread + context per device inside the
     library, column stripes, ONE ncclGather to devices[0], de-interleave on the way to the host).
@@ -412,7 +427,7 @@ def render_multi(devices, scene, epsilon, length, imageSize, camera, stripe_widt
     ctxs = (C.c_void_p * n)(*[d._ctx for d in devices])
     scs = (C.c_void_p * n)(*[s._scene for s in scenes])
     W, H = int(imageSize.X), int(imageSize.Y)
-    p = _lib.RenderParams(W, H, 0, W, int(stripe_width), 1, 0, 1, float(epsilon), float(length), 0, 0.0)
+    p = _lib.RenderParams(W, H, 0, W, int(stripe_width), 1, 0, 1, float(epsilon), float(length), 0, 0.0, 0, 0)
     out = np.empty((W, H, 3), np.float32)
     st = _lib.Stats()
     try:

@@ -46,6 +46,7 @@ struct ft_scene {
     ft::FlatScene flat;
     void* dBlob = nullptr;
     FtSceneDev dev{};
+    const float* dMaterialsExt = nullptr;    // EXTENSION table, handed to the kernel through FtRenderArgs
 };
 
 namespace {
@@ -129,7 +130,8 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     size_t cur = 0;
     const size_t oInstr = placed(cur, f.instr), oConsts = placed(cur, f.consts), oGrids = placed(cur, f.grids),
                  oKids = placed(cur, f.children), oCtr = placed(cur, f.cellCenters), oStart = placed(cur, f.cellStart),
-                 oItems = placed(cur, f.items), oLights = placed(cur, f.lights), oMats = placed(cur, f.materials);
+                 oItems = placed(cur, f.items), oLights = placed(cur, f.lights), oMats = placed(cur, f.materials),
+                 oMatX = placed(cur, f.materialsExt);
     std::vector<unsigned char> host(cur, 0);
     auto put = [&](size_t at, const void* p, size_t n) { if (n) memcpy(host.data() + at, p, n); };
     put(oInstr, f.instr.data(), f.instr.size() * sizeof(FtInstr));
@@ -141,11 +143,12 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     put(oItems, f.items.data(), f.items.size() * sizeof(FtItemRec));
     put(oLights, f.lights.data(), f.lights.size() * sizeof(FtLight));
     put(oMats, f.materials.data(), f.materials.size() * 4);
+    put(oMatX, f.materialsExt.data(), f.materialsExt.size() * 4);
     FtSceneDev& d = s->dev;
     d = FtSceneDev{};
     d.nInstr = (uint32_t)f.instr.size(); d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
-    d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ;
+    d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ; d.nGlass = f.nGlass;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));
@@ -160,6 +163,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d.items = reinterpret_cast<const FtItemRec*>(b + oItems);
     d.lights = reinterpret_cast<const FtLight*>(b + oLights);
     d.materials = reinterpret_cast<const float*>(b + oMats);
+    s->dMaterialsExt = reinterpret_cast<const float*>(b + oMatX);
     return FT_OK;
 }
 
@@ -176,7 +180,7 @@ int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
 // launch the persistent trace kernel over nJobs jobs
 int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     int perCU = 0;
-    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.spp != 1u || a.aoSamples != 0u, ldsBytes(s), &perCU));
+    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, ldsBytes(s), &perCU));
     perCU = std::max(1, std::min(perCU, 8));
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
@@ -190,6 +194,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     a.counter = c->dCounter;
     a.stats = c->dStats;
     a.S = s->dev;
+    a.materialsExt = s->dMaterialsExt;
     HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
     hipEvent_t e0, e1;
     int rc = acquireEvents(c, e0, e1); if (rc) return rc;
@@ -208,6 +213,9 @@ int checkParams(const ft_render_params* p) {
     int sn = 1; while (sn * sn < p->spp) ++sn;
     if (p->spp < 1 || p->spp > 64 || sn * sn != p->spp) return setErr(FT_ERR_INVALID, "spp (extension) must be a square number <= 64");
     if (p->ao_samples < 0 || p->ao_samples > 16) return setErr(FT_ERR_INVALID, "ao_samples (extension) must be in [0, 16]");
+    if (p->max_bounces < 0 || p->max_bounces > 64) return setErr(FT_ERR_INVALID, "max_bounces (extension) must be in [0, 64]");
+    if (p->spectral < 0 || p->spectral > 16 || (p->spectral > 0 && p->spp % p->spectral != 0))
+        return setErr(FT_ERR_INVALID, "spectral (extension) must be in [0, 16] and divide spp");
     // last local column must map inside the image
     const int64_t c = (int64_t)p->n_columns - 1;
     const int64_t x = p->x0 + (c / p->stripe_width) * (int64_t)p->stripe_width * p->stripe_ranks + (int64_t)p->stripe_rank * p->stripe_width + c % p->stripe_width;
@@ -315,6 +323,17 @@ int ft_form_boundary(ft_ctx* c, ft_handle form, ft_boundary* out) {
     return FT_OK;
 }
 ft_handle ft_material_solid(ft_ctx* c, const float rgb[3]) { CTX_OR_FAIL(c); if (!rgb) return setErr(FT_ERR_INVALID, "null colour"); return c->builder.materialSolid(tof3(rgb)); }
+ft_handle ft_material_glass(ft_ctx* c, const float tint[3], float ior, float dispersion) {
+    CTX_OR_FAIL(c); if (!tint) return setErr(FT_ERR_INVALID, "null colour");
+    return builderResult(c, c->builder.materialGlass(tof3(tint), ior, dispersion));
+}
+int ft_spectral_table(int32_t nw, float* out) {
+    if (!out || nw < 1 || nw > 16) return setErr(FT_ERR_INVALID, "1 <= nw <= 16 and a buffer of nw x 4 floats");
+    float t[16][4];
+    ft::spectralTable(nw, t);
+    memcpy(out, t, sizeof(float) * 4 * (size_t)nw);
+    return FT_OK;
+}
 ft_handle ft_object_create(ft_ctx* c, ft_handle material, ft_handle form) { CTX_OR_FAIL(c); return builderResult(c, c->builder.objectCreate(material, form)); }
 ft_handle ft_object_union(ft_ctx* c, const ft_handle* objs, int32_t n) { CTX_OR_FAIL(c); return builderResult(c, c->builder.objectUnion(objs, n)); }
 ft_handle ft_object_subtract(ft_ctx* c, ft_handle obj, ft_handle form) { CTX_OR_FAIL(c); return builderResult(c, c->builder.objectSubtract(obj, form)); }
@@ -394,6 +413,11 @@ int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const f
     a.aoSamples = (uint32_t)p->ao_samples; a.aoRadius = p->ao_radius;
     a.planePixels = (uint32_t)p->n_columns * (uint32_t)p->height;
     a.nJobs = a.jobsPerPlane * a.spp;
+    // EXTENSION glass / wavelengths: without a glass material in the scene bounces change nothing
+    a.maxBounces = s->dev.nGlass ? (uint32_t)p->max_bounces : 0u;
+    a.spectral = (uint32_t)p->spectral;
+    if (a.spectral) ft::spectralTable((int)a.spectral, a.spec);
+    a.ext = (a.spp != 1u || a.aoSamples != 0u || a.maxBounces != 0u || a.spectral != 0u) ? 1u : 0u;
     if (a.spp == 1) { a.out = static_cast<float*>(d_out); return launchTrace(c, s, a); }
     // EXTENSION: one frame per sample, then a fixed-order resolve
     const size_t planeFloats = (size_t)a.planePixels * 3;

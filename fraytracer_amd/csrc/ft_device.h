@@ -90,13 +90,13 @@ struct FtSceneDev {             // passed by value as kernel argument
     const uint32_t* cellStart;  // per grid: nCells+1 entries, absolute item indices
     const FtItemRec* items;
     const FtLight* lights;
-    const float* materials;     // 3 floats per material
+    const float* materials;     // 3 floats per material (colour, or tint of a glass)
     uint32_t nInstr, nSlots, nLights, fastPath;
     float bg[3];
     uint32_t nStage;            // leading floats of consts[] that every workgroup stages into LDS
     float nearR2;               // |p|^2 <= nearR2  =>  every t of the fast sphere runs is >= -87 (exp result normal)
     uint32_t fastQ;             // 1: every union candidate admits the clamped fast sqrt (scene.cpp: unionFastQ)
-    uint32_t pad1, pad2;
+    uint32_t nGlass, pad2;      // EXTENSION: glass materials in the scene
 };
 
 struct FtStatsDev {

@@ -22,7 +22,13 @@ struct FtRenderArgs {
     // EXTENSIONS (spp = 1, aoSamples = 0 is the reference): sample plane s of the frame is written at
     // out + s * planeFloats and resolved by ft_resolve_kernel; ambient-occlusion rays per primary hit
     uint32_t spp, sppN, aoSamples, jobsPerPlane;
-    float aoRadius; uint32_t planePixels, pad2, pad3;
+    float aoRadius; uint32_t planePixels;
+    uint32_t ext;             // 1: launch the EXTENSION build of the kernel (set by the host, see capi.cpp)
+    uint32_t maxBounces;      // EXTENSION glass: interactions per path; 0 = glass shades as a solid
+    uint32_t spectral, pad2;  // EXTENSION: wavelength bins (0 = off)
+    const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
+                                 // FtSceneDev so that the reference kernels' argument layout does not move
+    float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)
 };
 
 #ifdef __cplusplus

@@ -426,12 +426,28 @@ struct LaneState {
     f3 lint;              // intensity the current light adds when unshadowed
     float lcos;
     uint32_t aoIdx, aoOpen;   // EXTENSION: ambient-occlusion ray counter / unoccluded count
+    float sign;               // EXTENSION glass: +1 outside, -1 inside (the march runs on sign * Distance)
+    f3 thr;                   // EXTENSION: path throughput (wavelength weight x tints)
+    uint32_t bounce, seed;    // EXTENSION glass: interactions so far, per-sample hash seed
     uint32_t cEvals, cShadow, cHitP, cHitS, cPrimary, cFlags, cExt;
 };
 
 __device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx, f3 c) {
     float* o = out + 3ull * idx;
     o[0] = c.x; o[1] = c.y; o[2] = c.z;
+}
+
+// EXTENSION builds scale every finished sample by the path throughput (exactly 1 unless glass / wavelengths are on)
+template <bool EXT>
+__device__ __forceinline__ void emit(const FtRenderArgs& a, const LaneState& s, f3 c) {
+    write_rgb(a.out, s.outIdx, EXT ? c * s.thr : c);
+}
+
+// EXTENSION: lowbias32 of the sample seed and the bounce index (same function as the oracle's glass_hash)
+__device__ __forceinline__ uint32_t ft_glass_hash(uint32_t seed, uint32_t bounce) {
+    uint32_t h = seed + (bounce + 1u) * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
 }
 
 // advance a lane until it needs an SDF evaluation (or is idle): everything in SdfScene.trace that
@@ -442,7 +458,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
     for (;;) {
         if (s.phase == PH_MARCH) {
             if (s.len <= 0.0f) {                                       // SdfForm.fs:94 -> SdfScene.fs:10
-                write_rgb(a.out, s.outIdx, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
+                emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
                 s.phase = PH_IDLE;
             }
             return;
@@ -477,7 +493,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             if (s.lidx >= a.S.nLights) {                               // SdfScene.fs:28
                 cfp m = as_const(a.S.materials) + 3u * s.leaf;
                 const f3 color = mk3(m[0], m[1], m[2]);
-                write_rgb(a.out, s.outIdx, color * (s.lacc * piInv));
+                emit<EXT>(a, s, color * (s.lacc * piInv));
                 s.phase = PH_IDLE;
                 return;
             }
@@ -519,6 +535,7 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
         s.dir = mk3(r.direction.x, r.direction.y, r.direction.z);
         s.len = r.length; s.eps = r.epsilon;
         s.outIdx = s.job;
+        if (EXT) { s.thr = splat3(1.0f); s.seed = s.job; }
     } else {                                                           // Image.render (Image.fs:28-34)
         const uint32_t smp = EXT ? s.job / a.jobsPerPlane : 0u, jp = s.job - smp * a.jobsPerPlane;   // EXTENSION: sample plane (0 for spp = 1)
         const uint32_t t = jp >> 6, i = jp & 63u;
@@ -535,10 +552,65 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
         s.dir = ft_normalize(fw + (px - 0.5f) * rt + (py - 0.5f) * up);       // Camera.fs:48-51
         s.len = a.length; s.eps = a.eps;
         s.outIdx = smp * a.planePixels + cl * (uint32_t)a.H + y;
+        if (EXT) {                                                     // EXTENSION: wavelength weight, hash seed (global pixel)
+            s.thr = splat3(1.0f);
+            if (a.spectral != 0u) { const uint32_t bin = smp % a.spectral; s.thr = mk3(a.spec[bin][0], a.spec[bin][1], a.spec[bin][2]); }
+            s.seed = x * 0x9E3779B1u + y * 0x85EBCA77u + smp * 0xC2B2AE3Du;
+        }
     }
+    if (EXT) { s.sign = 1.0f; s.bounce = 0; }
     s.steps = 0; s.cPrimary += 1;
     s.phase = PH_MARCH;
     settle<EXT>(a, s);
+}
+
+// EXTENSION (BASELINE.json config 5): a path segment ended on leaf s.leaf with normal s.nrm at s.hp.  Glass leaf:
+// reflect or refract (Fresnel terms after the reference's dead Light.fs:30-59, repaired — see the oracle's
+// "EXTENSION ... glass" block for the definition this restates operation by operation) and march on.
+__device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s) {
+    cfp mx = as_const(a.materialsExt) + 4u * s.leaf;
+    const bool glass = mx[0] != 0.0f;
+    const f3 black = mk3(0.0f, 0.0f, 0.0f);
+    if (!glass) {
+        if (s.sign < 0.0f) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; }     // diffuse seen from inside: absorbed
+        return;
+    }
+    const f3 N = s.nrm, D = s.dir;
+    if (s.bounce >= a.maxBounces || N.x != N.x || N.y != N.y || N.z != N.z) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; return; }
+    float cosi = -ft_dot(N, D);
+    if (!(cosi > 0.0f)) cosi = 0.0f;
+    float n = mx[1];
+    if (a.spectral != 0u) {
+        const uint32_t smp = s.job / a.jobsPerPlane;
+        n = mx[1] + mx[2] * a.spec[smp % a.spectral][3];
+    }
+    const float n1 = s.sign > 0.0f ? 1.0f : n, n2 = s.sign > 0.0f ? n : 1.0f;
+    const float eta = n1 / n2;                                         // Light.fs:36
+    const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+    bool reflect = true;
+    float cost = 0.0f;
+    if (k >= 0.0f) {
+        cost = sqrtf(k);
+        float rs, rp;
+        { const float p = n2 * cosi, q = n1 * cost, x = (p - q) / (p + q); rs = x * x; }   // Light.fs:41-45
+        { const float p = n1 * cosi, q = n2 * cost, x = (p - q) / (p + q); rp = x * x; }   // Light.fs:47-51
+        const float reflectance = 0.5f * (rs + rp);                    // Light.fs:53
+        const float u = (float)(ft_glass_hash(s.seed, s.bounce) >> 8) * (1.0f / 16777216.0f);
+        reflect = u < reflectance;
+    }
+    s.cExt += 1;
+    if (reflect) {
+        s.dir = ft_normalize(D + N * (2.0f * cosi));                   // Light.fs:56
+        s.o = s.hp + N * (2.0f * s.eps);
+    } else {
+        s.dir = ft_normalize(D * eta + N * (eta * cosi - cost));       // Light.fs:58
+        s.o = s.hp - N * (4.0f * s.eps);
+        s.sign = -s.sign;
+        if (s.sign < 0.0f) { cfp t = as_const(a.S.materials) + 3u * s.leaf; s.thr = s.thr * mk3(t[0], t[1], t[2]); }
+    }
+    s.bounce += 1;
+    s.len = a.length; s.steps = 0;
+    s.phase = PH_MARCH;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
@@ -567,6 +639,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     s.len = 0; s.eps = 0; s.lcos = 0;
     s.cEvals = s.cShadow = s.cHitP = s.cHitS = s.cPrimary = s.cFlags = s.cExt = 0;
     s.aoIdx = s.aoOpen = 0;
+    s.sign = 1.0f; s.thr = splat3(1.0f); s.bounce = 0; s.seed = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk ------------------------------------------
@@ -608,6 +681,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
             else ft_eval(a.S, q, sd, sl, ldsC, d, leaf);
             s.cEvals += 1;
+            if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
 
             switch (s.phase) {
             case PH_MARCH:
@@ -638,6 +712,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 s.lidx = 0;
                 s.phase = PH_LIGHTS;
                 if (EXT && a.aoSamples != 0u) { s.aoIdx = 0; s.aoOpen = 0; s.phase = PH_AONEXT; }   // EXTENSION
+                if (EXT && a.maxBounces != 0u) glass_bounce(a, s);     // EXTENSION
                 break;
             }
             default: break;
@@ -803,7 +878,7 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
 // host-callable launchers (kept in this translation unit so the C ABI file is plain C++)
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
-    const bool ext = a->spp != 1u || a->aoSamples != 0u;
+    const bool ext = a->ext != 0u;
     if (a->S.fastPath == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (ext) hipLaunchKernelGGL(ft_trace_kernel_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (a->S.fastPath == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);

@@ -245,7 +245,14 @@ int Builder::formUnionSmooth(float strength, const int* kids, int n) { // SdfFor
 // ------------------------------------------------------------------------------------------------
 // SdfMaterial.fs:4-7, SdfObject.fs:6-64, SdfLight.fs:6-42
 // ------------------------------------------------------------------------------------------------
-int Builder::materialSolid(f3 rgb) { materials.push_back(rgb); return (int)materials.size() - 1; }
+int Builder::materialSolid(f3 rgb) { materials.push_back(rgb); materialExt.push_back(MatExt{}); return (int)materials.size() - 1; }
+int Builder::materialGlass(f3 tint, float ior, float dispersion) {     // EXTENSION (no counterpart in the reference)
+    if (!(ior > 0.0f)) { err = "glass: ior must be positive"; return FT_ERR_INVALID_; }
+    materials.push_back(tint);
+    MatExt e; e.glass = 1; e.ior = ior; e.dispersion = dispersion;
+    materialExt.push_back(e);
+    return (int)materials.size() - 1;
+}
 
 int Builder::objectCreate(int material, int form) {                    // SdfObject.fs:6-10
     if (material < 0 || (size_t)material >= materials.size() || !okForm(form)) { err = "invalid handle"; return FT_ERR_INVALID_; }
@@ -347,6 +354,10 @@ struct Flattener {
             matRemap[handle] = (int)(out.materials.size() / 3);
             const f3& m = b.materials[handle];
             out.materials.push_back(m.x); out.materials.push_back(m.y); out.materials.push_back(m.z);
+            const Builder::MatExt& e = b.materialExt[handle];
+            out.materialsExt.push_back(e.glass ? 1.0f : 0.0f); out.materialsExt.push_back(e.ior);
+            out.materialsExt.push_back(e.dispersion); out.materialsExt.push_back(0.0f);
+            out.nGlass += e.glass;
         }
         return (uint32_t)matRemap[handle];
     }
@@ -596,12 +607,33 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
         out.lights.push_back(b.lights[lights[i]].dev);
     }
-    if (out.materials.empty()) { out.materials.assign(3, 0.0f); }           // a form-only union under no create(): index 0 must exist
+    if (out.materials.empty()) { out.materials.assign(3, 0.0f); out.materialsExt.assign(4, 0.0f); }           // a form-only union under no create(): index 0 must exist
     out.bg[0] = bg[0]; out.bg[1] = bg[1]; out.bg[2] = bg[2];
     if (out.cellStart.empty()) out.cellStart.push_back(0);
     // keep every pool non-empty and padded so device-side wide loads never run off the end
     for (int i = 0; i < 64; ++i) out.consts.push_back(0.0f);
     return true;
+}
+
+void spectralTable(int nw, float out[][4]) {
+    // bin j looks at lambda_j = 400 + (j + 1/2) * 300 / nw nanometres.  Colour response: three tents
+    // (red 610 +- 120, green 540 +- 110, blue 460 +- 120 nm), each channel scaled so that its nw weights
+    // average exactly 1 in real arithmetic: without dispersion a spectral render reproduces the plain one.
+    static const double mid[3] = {610.0, 540.0, 460.0}, half[3] = {120.0, 110.0, 120.0};
+    double tent[16][3], total[3] = {0.0, 0.0, 0.0};
+    for (int j = 0; j < nw; ++j) {
+        const double nm = 400.0 + ((double)j + 0.5) * 300.0 / (double)nw;
+        for (int ch = 0; ch < 3; ++ch) {
+            const double off = nm < mid[ch] ? mid[ch] - nm : nm - mid[ch];
+            const double v = 1.0 - off / half[ch];
+            tent[j][ch] = v > 0.0 ? v : 0.0;
+            total[ch] += tent[j][ch];
+        }
+        const double um = nm / 1000.0;
+        out[j][3] = (float)(1.0 / (um * um) - 1.0 / (0.55 * 0.55));          // Cauchy term relative to 550 nm
+    }
+    for (int j = 0; j < nw; ++j)
+        for (int ch = 0; ch < 3; ++ch) out[j][ch] = (float)(tent[j][ch] * (double)nw / total[ch]);
 }
 
 float lensCreate(float fov) {                                          // Camera.fs:11-14

@@ -55,7 +55,9 @@ struct GridFiller {
 struct Builder {                                              // one per ft_ctx
     std::vector<HostForm> forms;
     std::vector<HostObject> objects;
-    std::vector<f3> materials;
+    std::vector<f3> materials;                                // colour (solid) or tint (glass)
+    struct MatExt { uint32_t glass = 0; float ior = 1.0f, dispersion = 0.0f; };
+    std::vector<MatExt> materialExt;                          // EXTENSION, same index as materials
     std::vector<HostLight> lights;
     std::string err;
     GridFiller* gridFiller = nullptr;                         // owned by the context; null = host build
@@ -70,6 +72,7 @@ struct Builder {                                              // one per ft_ctx
     int formIntersect(const int* kids, int n);
     int formUnionSmooth(float strength, const int* kids, int n);
     int materialSolid(f3 rgb);
+    int materialGlass(f3 tint, float ior, float dispersion);  // EXTENSION
     int objectCreate(int material, int form);
     int objectUnion(const int* objs, int n);
     int objectSubtract(int obj, int form);
@@ -91,6 +94,8 @@ struct FlatScene {                                            // host copy of ev
     std::vector<FtItemRec> items;
     std::vector<FtLight> lights;
     std::vector<float> materials;
+    std::vector<float> materialsExt;                          // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0)
+    uint32_t nGlass = 0;                                      // glass materials in this scene
     uint32_t nSlots = 1;
     uint32_t nStage = 0;                                      // consts[0, nStage) is mirrored in LDS by every workgroup
     float nearR2 = 0.0f;                                      // see FtSceneDev::nearR2
@@ -106,6 +111,10 @@ std::shared_ptr<HostGrid> buildSpatialLookup(const std::vector<Boundary>& bounds
 
 // flatten the tree under `object` (+ lights, background) into the device layout; false + err on failure
 bool flatten(const Builder& b, int object, const float bg[3], const int* lights, int nLights, FlatScene& out, std::string& err);
+
+// EXTENSION: wavelength bins of ft_render_params.spectral (rgb weight, Cauchy term); double arithmetic with
+// + - * / only, rounded once to float, so every host produces the same table
+void spectralTable(int nw, float out[][4]);
 
 float lensCreate(float fov);                                                              // Camera.fs:11-14
 void cameraLookAt(f3 pos, f3 lookAt, f3 up, float nearPlaneSize, f3 out[4]);              // Camera.fs:33-42

@@ -130,6 +130,31 @@ def config4(seed=3):
     return scene, ImageSize(8192, 8192)
 
 
+def config5(seed=5, size=2048, n_glass=6, n_solid=10, ior=1.5, dispersion=0.02):
+    """C5 (EXTENSION only, BASELINE.json config 5): glass spheres, tori and one smooth glass blob in front of
+    solid spheres; render with max_bounces = 4, spectral = 16, spp = 16."""
+    rng = Rng(seed)
+    objs = []
+    for i in range(n_glass):
+        tint = (rng.range(0.85, 1.0), rng.range(0.85, 1.0), rng.range(0.85, 1.0))
+        glass = SdfMaterial.createGlass(tint, ior, dispersion)
+        c = rng.pointInBall(3.0)
+        c = (c[0], c[1], c[2] * 0.5 - 1.5)                   # glass sits in front
+        if i % 3 == 0:
+            form = SdfForm.Primitive.torus(c, rng.pointOnSphere(1.0), rng.range(0.7, 1.1), rng.range(0.2, 0.35))
+        elif i % 3 == 1:
+            form = SdfForm.Primitive.sphere(c, rng.range(0.6, 1.1))
+        else:
+            kids = [SdfForm.Primitive.sphere((c[0] + rng.range(-0.6, 0.6), c[1] + rng.range(-0.6, 0.6), c[2] + rng.range(-0.3, 0.3)),
+                                             rng.range(0.35, 0.6)) for _ in range(4)]
+            form = SdfForm.unionSmooth(0.2, kids)
+        objs.append(SdfObject.create(glass, form))
+    for _ in range(n_solid):
+        c = rng.pointInBall(4.0)
+        objs.append(SdfObject.create(_material(rng), SdfForm.Primitive.sphere((c[0], c[1], abs(c[2]) + 1.0), rng.range(0.4, 1.0))))
+    return SdfScene(SdfObject.union(objs), BACKGROUND, program_lights()), ImageSize(size, size)
+
+
 def console_like(seed=19, n=1000, size=1000, factory=random_torus):
     """The structure of Program.fs:67-83 — subtract(intersect(union of n random tori, sphere r3.5),
     sphere r2.5) with the two lights — on the portable RNG (the System.Random-seeded original is

@@ -72,6 +72,10 @@ inline SdfFormV unionSmooth(float strength, const std::vector<SdfFormV>& forms) 
 
 namespace SdfMaterial {
 inline SdfMaterialV createSolid(const Context& c, FColor color) { return {check(ft_material_solid(c.get(), &color.v.x)), c.get()}; }
+// EXTENSION (not in the reference): refracting material, see ft_material_glass
+inline SdfMaterialV createGlass(const Context& c, FColor tint, float ior, float dispersion = 0.0f) {
+    return {check(ft_material_glass(c.get(), &tint.v.x, ior, dispersion)), c.get()};
+}
 }
 
 namespace SdfObject {
@@ -111,7 +115,7 @@ inline std::vector<float> renderScene(float epsilon, float length, ImageSize siz
     ft_scene* s = nullptr;
     check(ft_scene_create(ctx, scene.Object.Node, &scene.BackgroundColor.v.x, lights.data(), (int)lights.size(), &s));
     std::vector<float> out((size_t)size.X * size.Y * 3);
-    ft_render_params p{size.X, size.Y, 0, size.X, size.X, 1, 0, 1, epsilon, length, 0, 0.0f};
+    ft_render_params p{size.X, size.Y, 0, size.X, size.X, 1, 0, 1, epsilon, length, 0, 0.0f, 0, 0};
     ft_stats st{};
     int rc = ft_render(ctx, s, &camera, &p, out.data(), &st);
     ft_scene_destroy(s);

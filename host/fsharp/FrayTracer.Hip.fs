@@ -20,7 +20,8 @@ open FrayTracer
 type FtRenderParams =
     { Width : int; Height : int; X0 : int; NColumns : int
       StripeWidth : int; StripeRanks : int; StripeRank : int; Spp : int
-      Epsilon : float32; Length : float32; AoSamples : int; AoRadius : float32 }
+      Epsilon : float32; Length : float32; AoSamples : int; AoRadius : float32
+      MaxBounces : int; Spectral : int }
 
 [<Struct; StructLayout(LayoutKind.Sequential)>]
 type FtStats =
@@ -179,7 +180,8 @@ module Image =
                 let mutable p =
                     { Width = imageSize.X; Height = imageSize.Y; X0 = 0; NColumns = imageSize.X
                       StripeWidth = imageSize.X; StripeRanks = 1; StripeRank = 0; Spp = 1
-                      Epsilon = epsilon; Length = length; AoSamples = 0; AoRadius = 0f }
+                      Epsilon = epsilon; Length = length; AoSamples = 0; AoRadius = 0f
+                      MaxBounces = 0; Spectral = 0 }
                 let mutable stats = Unchecked.defaultof<FtStats>
                 Native.check (Native.ft_render (ctx, handle, &cam, &p, pin.AddrOfPinnedObject (), &stats)) |> ignore
                 image

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 1
+#define FT_ABI_VERSION 2
 
 typedef enum ft_status {
     FT_OK = 0,
@@ -71,6 +71,10 @@ typedef struct ft_render_params {
     float epsilon, length;        /* Image.render's first two arguments */
     int32_t ao_samples;           /* 0 = the reference. >0: EXTENSION ambient-occlusion rays */
     float ao_radius;
+    int32_t max_bounces;          /* 0 = the reference (glass shades as createSolid tint). >0: EXTENSION, glass
+                                   * materials refract / reflect; a path ends black after this many interactions */
+    int32_t spectral;             /* 0 = off. 1..16: EXTENSION, sample k is traced at wavelength bin k % spectral
+                                   * (must divide spp) and weighted with that bin's RGB response */
 } ft_render_params;
 
 typedef struct ft_stats {         /* filled per call; all counts are exact */
@@ -106,6 +110,12 @@ ft_handle ft_form_union_smooth(ft_ctx*, float strength, const ft_handle* forms, 
 int ft_form_boundary(ft_ctx*, ft_handle form, ft_boundary* out);           /* SdfForm.Boundary */
 
 ft_handle ft_material_solid(ft_ctx*, const float rgb[3]);                  /* SdfMaterial.createSolid SdfMaterial.fs:4-7 */
+/* EXTENSION (BASELINE.json config 5; the reference's SdfMaterial cannot spawn rays, Types.fs:46-49): glass with
+ * index of refraction `ior` at 550 nm and Cauchy dispersion n(lambda) = ior + dispersion * (1/lambda_um^2 - 1/0.55^2).
+ * Fresnel terms follow the reference's dead Light.fs:30-59 (repaired). */
+ft_handle ft_material_glass(ft_ctx*, const float tint[3], float ior, float dispersion);
+/* EXTENSION: the wavelength table behind ft_render_params.spectral = nw: out[nw][4] = RGB weight, Cauchy term */
+int ft_spectral_table(int32_t nw, float* out);
 ft_handle ft_object_create(ft_ctx*, ft_handle material, ft_handle form);   /* SdfObject.create    SdfObject.fs:6-10 */
 ft_handle ft_object_union(ft_ctx*, const ft_handle* objects, int32_t n);   /* SdfObject.union     SdfObject.fs:12-48 */
 ft_handle ft_object_subtract(ft_ctx*, ft_handle object, ft_handle form);   /* SdfObject.subtract  SdfObject.fs:50-54 */

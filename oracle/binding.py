@@ -60,7 +60,10 @@ def _load():
         "orc_trace_rays": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Counters)]),
         "orc_render": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
         "orc_render_strided": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
-        "orc_render_ext": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
+        "orc_render_ext": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(Counters)]),
+        "orc_material_glass": (C.c_int, [f3, C.c_float, C.c_float]),
+        "orc_spectral_table": (C.c_int, [C.c_int, C.c_void_p]), "orc_glass_hash": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+        "orc_fresnel": (None, [C.c_float, C.c_float, f3, f3, C.c_void_p]),
         "orc_pixel_ray": (None, [f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f3]),
     }
     for name, (res, args) in sig.items():
@@ -105,6 +108,7 @@ class Oracle:
     def form_intersect(self, hs): return _ck(lib.orc_form_intersect(*_hs(hs)))
     def form_union_smooth(self, k, hs): return _ck(lib.orc_form_union_smooth(k, *_hs(hs)))
     def material_solid(self, rgb): return _ck(lib.orc_material_solid(_f3(rgb)))
+    def material_glass(self, tint, ior, dispersion): return _ck(lib.orc_material_glass(_f3(tint), ior, dispersion))
     def object_create(self, m, f): return _ck(lib.orc_object_create(m, f))
     def object_union(self, hs): return _ck(lib.orc_object_union(*_hs(hs)))
     def object_subtract(self, o, f): return _ck(lib.orc_object_subtract(o, f))
@@ -157,7 +161,8 @@ class OracleScene:
         self.handle = handle
         self.object = obj
 
-    def render(self, epsilon, length, W, H, cam12, x0=0, x1=None, nthreads=None, xstep=1, spp=1, ao_samples=0, ao_radius=0.0):
+    def render(self, epsilon, length, W, H, cam12, x0=0, x1=None, nthreads=None, xstep=1, spp=1, ao_samples=0, ao_radius=0.0,
+               max_bounces=0, spectral=0):
         x1 = W if x1 is None else x1
         nthreads = nthreads or min(32, os.cpu_count() or 1)
         ncols = (x1 - x0 + xstep - 1) // xstep
@@ -165,7 +170,7 @@ class OracleScene:
         cnt = Counters()
         cam = (C.c_float * 12)(*[float(v) for v in cam12])
         _ck(lib.orc_render_ext(self.handle, cam, W, H, x0, x1, xstep, epsilon, length, spp, ao_samples, ao_radius,
-                               out.ctypes.data_as(C.c_void_p), nthreads, C.byref(cnt)))
+                               max_bounces, spectral, out.ctypes.data_as(C.c_void_p), nthreads, C.byref(cnt)))
         return out, cnt.as_dict()
 
     def trace_rays(self, rays):
@@ -174,6 +179,24 @@ class OracleScene:
         cnt = Counters()
         _ck(lib.orc_trace_rays(self.handle, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p), C.byref(cnt)))
         return out, cnt.as_dict()
+
+
+def spectral_table(nw):
+    """EXTENSION: (nw, 4) float32 — rgb weight and Cauchy term of every wavelength bin"""
+    out = np.empty((nw, 4), np.float32)
+    _ck(lib.orc_spectral_table(nw, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def fresnel(n1, n2, N, D):
+    """EXTENSION: {'reflectance', 'total', 'reflect', 'transmit'} of the oracle's repaired Light.fs:30-59"""
+    out = np.empty(8, np.float32)
+    lib.orc_fresnel(n1, n2, _f3(N), _f3(D), out.ctypes.data_as(C.c_void_p))
+    return {"reflectance": float(out[0]), "total": bool(out[1]), "reflect": out[2:5].copy(), "transmit": out[5:8].copy()}
+
+
+def glass_hash(seed, bounce):
+    return int(lib.orc_glass_hash(seed & 0xFFFFFFFF, bounce))
 
 
 def lens_create(fov):

@@ -207,7 +207,11 @@ struct SdfForm {                                                            // T
     SdfBoundary Boundary;
     std::shared_ptr<GridDump> grid;   // oracle-only: lets tests inspect the union's lookup
 };
-struct SdfMaterial { std::function<FColor(V3, V3)> Color; };                // Types.fs:46-49
+struct GlassParams { float Ior, Dispersion; V3 Tint; };                     // EXTENSION (not in the reference)
+struct SdfMaterial {                                                        // Types.fs:46-49
+    std::function<FColor(V3, V3)> Color;
+    std::function<const GlassParams*(V3)> Glass;   // EXTENSION: empty / nullptr = an ordinary (solid) material
+};
 struct SdfObject { SdfForm Form; SdfMaterial Material; };                   // Types.fs:51-55
 struct SdfObjectTraceResult { Ray ray; V3 Normal; FColor Color; };          // Types.fs:57-65
 struct SdfLight {                                                           // Types.fs:67-72
@@ -541,7 +545,12 @@ SdfForm Prim_box(V3 Center, V3 Half) {
 // SdfMaterial.fs:4-10, SdfObject.fs:6-78
 // ---------------------------------------------------------------------------
 SdfMaterial Material_createSolid(FColor color) {                             // SdfMaterial.fs:4-7
-    return SdfMaterial{[color](V3, V3) { return color; }};
+    return SdfMaterial{[color](V3, V3) { return color; }, nullptr};
+}
+// EXTENSION: glass.  Shades as createSolid(tint) wherever bounces are off (max_bounces = 0).
+SdfMaterial Material_createGlass(FColor tint, float ior, float dispersion) {
+    auto g = std::make_shared<GlassParams>(GlassParams{ior, dispersion, tint.c});
+    return SdfMaterial{[tint](V3, V3) { return tint; }, [g](V3) -> const GlassParams* { return g.get(); }};
 }
 SdfObject Object_create(const SdfMaterial& material, const SdfForm& form) {  // SdfObject.fs:6-10
     return SdfObject{form, material};
@@ -556,9 +565,10 @@ SdfObject Object_union(const std::vector<SdfObject>& objects, std::string& err) 
     std::vector<SdfBoundary> bs; for (auto& o : objects) bs.push_back(o.Form.Boundary);
     auto grid = buildSpatialLookup(bs);                                      // :26 (second, identical grid)
     auto objs = std::make_shared<std::vector<SdfObject>>(objects);
-    out.Material.Color = [grid, objs](V3 position, V3 normal) -> FColor {
+    // the argmin of SdfObject.fs:27-46, shared by Color and by the EXTENSION hook Glass
+    auto pick = [grid, objs](V3 position) -> const SdfObject* {
         const LookupCell& cell = grid->lookup(position);                     // :28
-        const SdfMaterial* material = &(*objs)[cell.Items[0].Item].Material; // :29
+        const SdfObject* material = &(*objs)[cell.Items[0].Item];            // :29
         float min = (*objs)[cell.Items[0].Item].Form.Distance(position);     // :30
         float distanceToCenter = Distance(cell.Center, position);            // :32
         for (size_t i = 0; i < cell.Items.size(); ++i) {                     // :34 (from 0)
@@ -567,10 +577,17 @@ SdfObject Object_union(const std::vector<SdfObject>& objects, std::string& err) 
             if (min > sdf.LowerBound - distanceToCenter                      // :37
                 && min > getMinDistance(item.Form.Boundary, position)) {     // :38
                 float distance = item.Form.Distance(position);               // :40
-                if (distance < min) { min = distance; material = &item.Material; }  // :41-43
+                if (distance < min) { min = distance; material = &item; }    // :41-43
             }
         }
-        return material->Color(position, normal);                            // :45-46
+        return material;
+    };
+    out.Material.Color = [pick](V3 position, V3 normal) -> FColor {
+        return pick(position)->Material.Color(position, normal);             // :45-46
+    };
+    out.Material.Glass = [pick](V3 position) -> const GlassParams* {         // EXTENSION
+        const SdfObject* o = pick(position);
+        return o->Material.Glass ? o->Material.Glass(position) : nullptr;
     };
     return out;
 }
@@ -671,31 +688,164 @@ const float AO_DIRS[16][3] = {
     {0x1.046c0ap-3f, 0x1.a248a2p-1f, -0x1.200000p-1f}, {0x1.9bff54p-2f, -0x1.3585eap-1f, -0x1.600000p-1f},
     {-0x1.21c850p-1f, 0x1.1e0d66p-3f, -0x1.a00000p-1f}, {0x1.38c4f8p-2f, 0x1.55799ap-3f, -0x1.e00000p-1f}};
 
+// ---------------------------------------------------------------------------
+// EXTENSION (BASELINE.json config 5; nothing like it runs in the reference): glass with refraction,
+// reflection and per-wavelength dispersion.  The only related reference text is the dead `fresnel` in
+// Light.fs:30-59; its reflectance expressions (:41-53) and reflect / transmit vectors (:56, :58) are kept,
+// with two repairs: cos(theta_i) is taken against the incoming direction (cosi = -dot(N, D), N facing the
+// ray), and cos(theta_t) is Snell's sqrt(1 - eta^2 (1 - cosi^2)) (the text's `1 + eta cosi^2 - eta` is not).
+// Definition (one path per sample, no ray tree):
+//   * f = sign * Distance, sign = +1 outside / -1 inside glass; SdfForm.tryTrace and normalFromRay run on f.
+//   * hit on a non-glass leaf: outside -> the reference's shading (incl. AO extension); inside -> absorbed (black).
+//   * hit on a glass leaf (material picked at the hit origin like SdfObject.fs:75): after max_bounces glass
+//     interactions the path ends black.  n = Ior + Dispersion * cauchy(bin) (Cauchy, relative to 550 nm);
+//     eta = n1 / n2; total internal reflection when 1 - eta^2 (1 - cosi^2) < 0; otherwise reflect iff
+//     u < Reflectance with u = top 24 bits of lowbias32(seed + (bounce + 1) * 0x27D4EB2F) * 2^-24,
+//     seed = x * 0x9E3779B1 + y * 0x85EBCA77 + sample * 0xC2B2AE3D (global pixel coordinates).
+//     reflect:  Direction = normalize(D + N * (2 cosi)),                   Origin = hit + N * (2 eps)
+//     transmit: Direction = normalize(D * eta + N * (eta cosi - cost)),   Origin = hit - N * (4 eps), sign flips,
+//               throughput *= Tint when entering.   Length = the primary ray's Length again.
+//   * sample value = (background | shaded colour) * throughput; throughput starts as the sample's wavelength
+//     weight (1 when spectral = 0).  Sample k uses wavelength bin k % spectral.
+//   * wavelength bins: lambda_j = 400 + (j + 1/2) 300 / spectral nm; RGB response = tents (610+-120, 540+-110,
+//     460+-120) normalised so that each channel's weights average 1; cauchy_j = 1/lambda_um^2 - 1/0.55^2.
+//     Only + - * / in double, then one rounding to float: identical on every host.
+// max_bounces = 0 renders glass as createSolid(Tint), i.e. the reference's path.
+// ---------------------------------------------------------------------------
+struct SpectralBin { V3 weight; float cauchy; };
+
+void spectral_table(int nw, SpectralBin out[16]) {
+    const double centre[3] = {610.0, 540.0, 460.0}, width[3] = {120.0, 110.0, 120.0};
+    double resp[16][3], sum[3] = {0.0, 0.0, 0.0};
+    for (int j = 0; j < nw; ++j) {
+        const double lambda = 400.0 + ((double)j + 0.5) * 300.0 / (double)nw;
+        for (int c = 0; c < 3; ++c) {
+            double d = lambda - centre[c]; if (d < 0.0) d = -d;
+            double t = 1.0 - d / width[c]; if (t < 0.0) t = 0.0;
+            resp[j][c] = t; sum[c] += t;
+        }
+        const double um = lambda / 1000.0;
+        out[j].cauchy = (float)(1.0 / (um * um) - 1.0 / (0.55 * 0.55));
+    }
+    for (int j = 0; j < nw; ++j) {
+        float w[3];
+        for (int c = 0; c < 3; ++c) w[c] = (float)(resp[j][c] * (double)nw / sum[c]);
+        out[j].weight = v3(w[0], w[1], w[2]);
+    }
+}
+
+inline uint32_t glass_hash(uint32_t seed, uint32_t bounce) {
+    uint32_t h = seed + (bounce + 1u) * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+// Light.fs:28-59 with the two repairs named above; N faces the incoming direction D.  `total` = total internal
+// reflection (Reflectance 1, no Transmit).
+struct Fresnel { float Reflectance; bool total; V3 Reflect, Transmit; };
+Fresnel fresnel_ext(float n1, float n2, V3 N, V3 D) {
+    Fresnel out;
+    float cosi = -Dot(N, D);
+    if (!(cosi > 0.0f)) cosi = 0.0f;
+    const float eta = n1 / n2;                                               // Light.fs:36
+    const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+    out.Reflect = Normalize(D + N * (2.0f * cosi));                          // Light.fs:56
+    out.total = !(k >= 0.0f);
+    if (out.total) { out.Reflectance = 1.0f; out.Transmit = v3s(0.0f); return out; }
+    const float cost = sqrtf(k);
+    float rs, rp;
+    { const float a = n2 * cosi, b = n1 * cost, x = (a - b) / (a + b); rs = x * x; }   // Light.fs:41-45
+    { const float a = n1 * cosi, b = n2 * cost, x = (a - b) / (a + b); rp = x * x; }   // Light.fs:47-51
+    out.Reflectance = 0.5f * (rs + rp);                                      // Light.fs:53
+    out.Transmit = Normalize(D * eta + N * (eta * cosi - cost));             // Light.fs:58
+    return out;
+}
+
+// SdfScene.fs:12-28 on an already traced hit, with the ambient-occlusion extension in front
+FColor Scene_shade_ext(const SdfScene& scene, const Ray& hit, V3 Normal, FColor Color, int aoSamples, float aoRadius) {
+    FColor lightColor = scene.BackgroundColor;                               // :12
+    if (aoSamples > 0) {
+        int open = 0;
+        for (int k = 0; k < aoSamples; ++k) {
+            V3 dir = Normalize(Normal + v3(AO_DIRS[k][0], AO_DIRS[k][1], AO_DIRS[k][2]));
+            tl_cnt.rays_ext++;
+            if (dir.X != dir.X || dir.Y != dir.Y || dir.Z != dir.Z) { open++; continue; }
+            Ray r{hit.Origin, dir, aoRadius, hit.Epsilon};
+            SdfFormTraceResult tr;
+            if (!Form_tryTrace(scene.Object.Form, r, tr)) open++;
+        }
+        lightColor = scene.BackgroundColor * ((float)open / (float)aoSamples);
+    }
+    for (const SdfLight& light : scene.Lights) {                             // :13-26
+        V3 lightDirection = light.Direction(hit.Origin);
+        float lightCos = Dot(Normal, lightDirection);
+        if (lightCos > 0.0f) {
+            FColor intensity;
+            if (light.Intensity(scene.Object, hit, intensity)) lightColor = lightColor + intensity * lightCos;
+        }
+    }
+    return Color * (lightColor * piInv);                                     // :28
+}
+
 FColor Scene_trace_ext(const SdfScene& scene, const Ray& ray, int aoSamples, float aoRadius) {
     if (aoSamples <= 0) return Scene_trace(scene, ray);
     SdfObjectTraceResult result;
     tl_cnt.rays_primary++;
     if (!Object_tryTrace(scene.Object, ray, result)) return scene.BackgroundColor;
     tl_cnt.hits_primary++;
-    int open = 0;
-    for (int k = 0; k < aoSamples; ++k) {
-        V3 dir = Normalize(result.Normal + v3(AO_DIRS[k][0], AO_DIRS[k][1], AO_DIRS[k][2]));
-        tl_cnt.rays_ext++;
-        if (dir.X != dir.X || dir.Y != dir.Y || dir.Z != dir.Z) { open++; continue; }
-        Ray r{result.ray.Origin, dir, aoRadius, ray.Epsilon};
-        SdfFormTraceResult tr;
-        if (!Form_tryTrace(scene.Object.Form, r, tr)) open++;
-    }
-    FColor lightColor = scene.BackgroundColor * ((float)open / (float)aoSamples);
-    for (const SdfLight& light : scene.Lights) {                             // SdfScene.fs:13-26 unchanged
-        V3 lightDirection = light.Direction(result.ray.Origin);
-        float lightCos = Dot(result.Normal, lightDirection);
-        if (lightCos > 0.0f) {
-            FColor intensity;
-            if (light.Intensity(scene.Object, result.ray, intensity)) lightColor = lightColor + intensity * lightCos;
+    return Scene_shade_ext(scene, result.ray, result.Normal, result.Color, aoSamples, aoRadius);
+}
+
+FColor Scene_trace_path(const SdfScene& scene, Ray ray, int aoSamples, float aoRadius, int maxBounces,
+                        uint32_t seed, const SpectralBin* bin) {
+    const FColor black{v3s(0.0f)};
+    const float length0 = ray.Length;
+    V3 thr = bin ? bin->weight : v3s(1.0f);
+    float sign = 1.0f;
+    uint32_t bounce = 0;
+    tl_cnt.rays_primary++;
+    const SdfForm& outer = scene.Object.Form;
+    SdfForm inner;
+    inner.Distance = [&outer](V3 p) { return -outer.Distance(p); };
+    inner.Boundary = outer.Boundary;
+    for (;;) {
+        const SdfForm& form = sign < 0.0f ? inner : outer;
+        SdfFormTraceResult res;
+        if (!Form_tryTrace(form, ray, res)) return FColor{scene.BackgroundColor.c * thr};
+        tl_cnt.hits_primary++;
+        const V3 N = Form_normalFromRay(form, res.ray);
+        const Ray hit = Ray_move(-ray.Epsilon, res.ray);
+        const GlassParams* g = (maxBounces > 0 && scene.Object.Material.Glass) ? scene.Object.Material.Glass(res.ray.Origin) : nullptr;
+        if (!g) {
+            if (sign < 0.0f) return black;                                   // a diffuse surface seen from inside glass: absorbed
+            const FColor color = scene.Object.Material.Color(res.ray.Origin, N);
+            return FColor{Scene_shade_ext(scene, hit, N, color, aoSamples, aoRadius).c * thr};
         }
+        if (bounce >= (uint32_t)maxBounces) return black;
+        if (N.X != N.X || N.Y != N.Y || N.Z != N.Z) return black;
+        const V3 D = ray.Direction;
+        const float n = bin ? g->Ior + g->Dispersion * bin->cauchy : g->Ior;
+        const Fresnel f = fresnel_ext(sign > 0.0f ? 1.0f : n, sign > 0.0f ? n : 1.0f, N, D);
+        bool reflect = true;
+        if (!f.total) {
+            const float u = (float)(glass_hash(seed, bounce) >> 8) * (1.0f / 16777216.0f);
+            reflect = u < f.Reflectance;
+        }
+        tl_cnt.rays_ext++;
+        Ray next;
+        next.Epsilon = ray.Epsilon; next.Length = length0;
+        if (reflect) {
+            next.Direction = f.Reflect;
+            next.Origin = hit.Origin + N * (2.0f * ray.Epsilon);
+        } else {
+            next.Direction = f.Transmit;
+            next.Origin = hit.Origin - N * (4.0f * ray.Epsilon);
+            sign = -sign;
+            if (sign < 0.0f) thr = thr * g->Tint;
+        }
+        bounce++;
+        ray = next;
     }
-    return result.Color * (lightColor * piInv);
 }
 
 // ---------------------------------------------------------------------------
@@ -846,6 +996,24 @@ int orc_form_grid_dump(int form, uint32_t* cell_start, float* centers, float* lo
 int orc_material_solid(const float rgb[3]) {
     g_materials.push_back(Material_createSolid(FColor{ld3(rgb)})); return (int)g_materials.size() - 1;
 }
+int orc_material_glass(const float tint[3], float ior, float dispersion) {       // EXTENSION
+    g_materials.push_back(Material_createGlass(FColor{ld3(tint)}, ior, dispersion)); return (int)g_materials.size() - 1;
+}
+// EXTENSION: the wavelength table (nw x 4 floats: weight rgb, cauchy term)
+int orc_spectral_table(int nw, float* out) {
+    if (nw < 1 || nw > 16) return fail("1 <= nw <= 16");
+    SpectralBin b[16]; spectral_table(nw, b);
+    for (int j = 0; j < nw; ++j) { out[4 * j] = b[j].weight.X; out[4 * j + 1] = b[j].weight.Y; out[4 * j + 2] = b[j].weight.Z; out[4 * j + 3] = b[j].cauchy; }
+    return 0;
+}
+uint32_t orc_glass_hash(uint32_t seed, uint32_t bounce) { return glass_hash(seed, bounce); }
+// EXTENSION: out = Reflectance, total (0/1), Reflect xyz, Transmit xyz
+void orc_fresnel(float n1, float n2, const float N[3], const float D[3], float out[8]) {
+    const Fresnel f = fresnel_ext(n1, n2, ld3(N), ld3(D));
+    out[0] = f.Reflectance; out[1] = f.total ? 1.0f : 0.0f;
+    out[2] = f.Reflect.X; out[3] = f.Reflect.Y; out[4] = f.Reflect.Z;
+    out[5] = f.Transmit.X; out[6] = f.Transmit.Y; out[7] = f.Transmit.Z;
+}
 int orc_object_create(int material, int form) {
     if (material < 0 || (size_t)material >= g_materials.size() || !okf(form)) return fail("bad handle");
     g_objects.push_back(Object_create(g_materials[material], g_forms[form])); return (int)g_objects.size() - 1;
@@ -920,19 +1088,27 @@ int orc_trace_rays(int scene, const float* rays, int64_t n, float* out, orc_coun
 // (x1-x0) x H x 3 floats, x-major / y contiguous like FColor[X,Y] (Array2D.fs:30-38).
 // Threading mirrors Array2D.fs:32: workers pull whole x-columns.
 int orc_render_ext(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
-               float epsilon, float length, int spp, int aoSamples, float aoRadius, float* out, int nthreads, orc_counters* cnt);
+               float epsilon, float length, int spp, int aoSamples, float aoRadius, int maxBounces, int spectral,
+               float* out, int nthreads, orc_counters* cnt);
 
 // `xstep` > 1 renders only columns x0, x0+xstep, ... (< x1): the bounded sample bench.py times.
 int orc_render_strided(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
                float epsilon, float length, float* out, int nthreads, orc_counters* cnt) {
-    return orc_render_ext(scene, cam, W, H, x0, x1, xstep, epsilon, length, 1, 0, 0.0f, out, nthreads, cnt);
+    return orc_render_ext(scene, cam, W, H, x0, x1, xstep, epsilon, length, 1, 0, 0.0f, 0, 0, out, nthreads, cnt);
 }
 
-// spp / aoSamples: EXTENSIONS (see Scene_trace_ext); spp = 1, aoSamples = 0 is the reference's Image.render
+// spp / aoSamples / maxBounces / spectral: EXTENSIONS (see Scene_trace_ext, Scene_trace_path); all at their
+// neutral values (1, 0, 0, 0) is the reference's Image.render
 int orc_render_ext(int scene, const float cam[12], int W, int H, int x0, int x1, int xstep,
-               float epsilon, float length, int spp, int aoSamples, float aoRadius, float* out, int nthreads, orc_counters* cnt) {
+               float epsilon, float length, int spp, int aoSamples, float aoRadius, int maxBounces, int spectral,
+               float* out, int nthreads, orc_counters* cnt) {
     int sn = 1; while (sn * sn < spp) ++sn;
     if (spp < 1 || sn * sn != spp || aoSamples < 0 || aoSamples > 16) return fail("spp must be a square, ao_samples <= 16");
+    if (maxBounces < 0 || maxBounces > 64 || spectral < 0 || spectral > 16 || (spectral > 0 && spp % spectral != 0))
+        return fail("max_bounces <= 64, spectral <= 16 and a divisor of spp");
+    SpectralBin bins[16];
+    if (spectral > 0) spectral_table(spectral, bins);
+    const bool path = maxBounces > 0 || spectral > 0;
     if (scene < 0 || (size_t)scene >= g_scenes.size()) return fail("bad scene handle");
     if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1 || xstep < 1) return fail("bad image range");
     const SdfScene& sc = g_scenes[scene];
@@ -949,7 +1125,7 @@ int orc_render_ext(int scene, const float cam[12], int W, int H, int x0, int x1,
             if (x >= x1) break;
             for (int y = 0; y < H; ++y) {                                    // Array2D.fs:33
                 FColor c{v3s(0.0f)};
-                if (spp == 1 && aoSamples == 0) {
+                if (spp == 1 && aoSamples == 0 && !path) {
                     V2 pos{(float)x / maxSize, (float)y / maxSize};          // Image.fs:20-23,30
                     Ray ray = Camera_uniformPixelToRay(epsilon, length, camera, pos);  // Image.fs:32
                     c = Scene_trace(sc, ray);                                // Image.fs:34
@@ -957,7 +1133,9 @@ int orc_render_ext(int scene, const float cam[12], int W, int H, int x0, int x1,
                     for (int k = 0; k < spp; ++k) {
                         V2 pos{((float)x + (float)(k % sn) / (float)sn) / maxSize, ((float)y + (float)(k / sn) / (float)sn) / maxSize};
                         Ray ray = Camera_uniformPixelToRay(epsilon, length, camera, pos);
-                        FColor sc_ = Scene_trace_ext(sc, ray, aoSamples, aoRadius);
+                        const uint32_t seed = (uint32_t)x * 0x9E3779B1u + (uint32_t)y * 0x85EBCA77u + (uint32_t)k * 0xC2B2AE3Du;
+                        FColor sc_ = path ? Scene_trace_path(sc, ray, aoSamples, aoRadius, maxBounces, seed, spectral > 0 ? &bins[k % spectral] : nullptr)
+                                          : Scene_trace_ext(sc, ray, aoSamples, aoRadius);
                         c = k == 0 ? sc_ : c + sc_;
                     }
                     if (spp > 1) c = c / (float)spp;

@@ -34,8 +34,8 @@ def test_blittable_layouts_match_the_reference_records():
     # Types.fs:9-24 Ray 32 B / SdfBoundary 16 B; Camera.fs:16-22 48 B; primitive structs SdfForm.fs:118-212
     assert C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Boundary) == 16 and C.sizeof(_lib.CameraS) == 48
     assert C.sizeof(_lib.Sphere) == 16 and C.sizeof(_lib.Capsule) == 28 and C.sizeof(_lib.Torus) == 32 and C.sizeof(_lib.Triangle) == 40
-    assert C.sizeof(_lib.RenderParams) == 48 and C.sizeof(_lib.Stats) == 72
-    assert _lib.lib.ft_abi_version() == 1
+    assert C.sizeof(_lib.RenderParams) == 56 and C.sizeof(_lib.Stats) == 72
+    assert _lib.lib.ft_abi_version() == 2
 
 
 def test_the_library_is_built_in_tree_and_is_not_the_oracle():

@@ -256,6 +256,78 @@ def test_extension_defaults_are_the_reference_path(gpu):
         ds.render(EPS, LEN, ft.ImageSize(8, 8), cam, spp=3)
 
 
+def glass_blob_scene(n=24, seed=31, disp=0.03):
+    """one glass object that is a smooth union of spheres (-> the shape-specialised kernel's EXTENSION build)"""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    rng = syn.Rng(seed)
+    kids = [SdfForm.Primitive.sphere(rng.pointInBall(2.5), rng.range(0.4, 0.9)) for _ in range(n)]
+    obj = SdfObject.create(SdfMaterial.createGlass((0.95, 0.9, 0.8), 1.45, disp), SdfForm.unionSmooth(0.25, kids))
+    return SdfScene(obj, syn.BACKGROUND, syn.program_lights())
+
+
+@pytest.mark.parametrize("spp,spectral,bounces,ao", [(1, 0, 4, 0), (4, 4, 4, 0), (16, 16, 4, 0), (4, 2, 1, 0), (4, 4, 6, 4), (1, 1, 2, 0)])
+def test_extension_glass_paths(gpu, oracle, spp, spectral, bounces, ao):
+    """EXTENSION (BASELINE.json config 5): refraction / reflection / wavelength bins, defined by the oracle
+    (tests/test_oracle_glass_ext.py pins that definition); the kernel must reproduce it bit for bit, ray for ray."""
+    cam = syn.default_camera()
+    for scene, n in ((syn.config5(size=72)[0], 72), (glass_blob_scene(), 56)):
+        ds, os_ = both(gpu, oracle, scene)
+        kw = dict(spp=spp, spectral=spectral, max_bounces=bounces, ao_samples=ao, ao_radius=0.5)
+        g, gst = ds.render(EPS, LEN, ft.ImageSize(n, n), cam, **kw)
+        o, ocnt = os_.render(EPS, LEN, n, n, cam.as_array(), **kw)
+        assert_bit_equal(g, o, f"glass spp={spp} spectral={spectral} bounces={bounces} ao={ao}")
+        for k in ("rays_primary", "rays_ext", "rays_shadow", "hits_primary", "hits_shadow"):
+            assert gst[k] == ocnt[k], k
+        assert gst["rays_ext"] > n * n // 20 and gst["flags"] == ocnt["flags"] == 0
+
+
+def test_extension_glass_degenerate_cases(gpu, oracle):
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    cam = syn.default_camera()
+    scene, _ = syn.config5(size=64)
+    ds, os_ = both(gpu, oracle, scene)
+    # max_bounces = 0: glass is createSolid(tint) and runs on the reference kernel
+    g0, _ = ds.render(EPS, LEN, ft.ImageSize(64, 64), cam)
+    o0, _ = os_.render(EPS, LEN, 64, 64, cam.as_array())
+    assert_bit_equal(g0, o0, "glass with max_bounces = 0")
+    # column stripes of a glass frame (multi-GPU tiling): seeds hang on global pixel coordinates
+    full, _ = ds.render(EPS, LEN, ft.ImageSize(64, 64), cam, spp=4, spectral=4, max_bounces=4)
+    parts = [ds.render(EPS, LEN, ft.ImageSize(64, 64), cam, spp=4, spectral=4, max_bounces=4,
+                       stripe_width=8, stripe_ranks=2, stripe_rank=r)[0] for r in range(2)]
+    inter = np.empty_like(full)
+    for r in range(2):
+        for b in range(4):
+            inter[(2 * b + r) * 8:(2 * b + r + 1) * 8] = parts[r][b * 8:(b + 1) * 8]
+    assert_bit_equal(inter, full, "striped glass render")
+    # bounces on a scene without glass change nothing
+    plain, _ = syn.config2(seed=4)
+    dp = gpu.scene(plain)
+    a, _ = dp.render(EPS, LEN, ft.ImageSize(48, 48), cam)
+    b, _ = dp.render(EPS, LEN, ft.ImageSize(48, 48), cam, max_bounces=4)
+    assert_bit_equal(a, b, "max_bounces without glass")
+    for kw in (dict(spectral=3, spp=4), dict(spectral=17), dict(max_bounces=-1), dict(max_bounces=65)):
+        with pytest.raises(ft.FrayTracerError):
+            ds.render(EPS, LEN, ft.ImageSize(8, 8), cam, **kw)
+    with pytest.raises(ft.FrayTracerError):
+        gpu.scene(SdfScene(SdfObject.create(SdfMaterial.createGlass((1, 1, 1), 0.0), SdfForm.Primitive.sphere((0, 0, 0), 1.0)), syn.BACKGROUND, []))
+
+
+def test_extension_glass_full_size_properties(gpu):
+    """BASELINE.json config 5 at its full size (2048^2, 16 spp, 4 bounces, 16 wavelength bins): finite, bounded
+    by the brightest solid shading, deterministic (two runs agree bit for bit)."""
+    scene, size = syn.config5()
+    cam = syn.default_camera()
+    ds = gpu.scene(scene)
+    kw = dict(spp=16, spectral=16, max_bounces=4)
+    a, st = ds.render(EPS, LEN, size, cam, **kw)
+    b, _ = ds.render(EPS, LEN, size, cam, **kw)
+    assert_bit_equal(a, b, "config 5 twice")
+    assert np.isfinite(a).all() and a.min() >= 0.0 and st["flags"] == 0
+    assert st["rays_primary"] == size.X * size.Y * 16 and st["rays_ext"] > st["rays_primary"] // 10
+    solid, _ = ds.render(EPS, LEN, size, cam)
+    assert a.max() <= solid.max() * 2.9          # a wavelength weight is below 2.9 (ft_spectral_table(16))
+
+
 def test_nan_distances_are_flagged_identically(gpu, oracle):
     """A degenerate capsule (From == To -> dirInv = 0/0) has a NaN distance.  The reference would spin
     forever in SdfForm.tryTrace; oracle and kernel both resolve such rays as misses and raise flag bit 0."""
