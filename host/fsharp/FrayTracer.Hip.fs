@@ -45,6 +45,7 @@ module Native =
     [<DllImport(Lib)>] extern int ft_form_intersect(nativeint ctx, int[] forms, int n)
     [<DllImport(Lib)>] extern int ft_form_union_smooth(nativeint ctx, float32 strength, int[] forms, int n)
     [<DllImport(Lib)>] extern int ft_material_solid(nativeint ctx, Vector3& rgb)
+    [<DllImport(Lib)>] extern int ft_material_glass(nativeint ctx, Vector3& tint, float32 ior, float32 dispersion)
     [<DllImport(Lib)>] extern int ft_object_create(nativeint ctx, int material, int form)
     [<DllImport(Lib)>] extern int ft_object_union(nativeint ctx, int[] objects, int n)
     [<DllImport(Lib)>] extern int ft_object_subtract(nativeint ctx, int obj, int form)
@@ -121,6 +122,12 @@ module SdfMaterial =
     let createSolid (color : FColor) =                                                           // SdfMaterial.fs:4-7
         let mutable rgb = let (FColor v) = color in v
         { Material = SdfMaterial.createSolid color; Node = Native.check (Native.ft_material_solid (Native.ctx.Value, &rgb)) }
+
+    /// EXTENSION (no reference counterpart): glass.  The CPU closure is the solid tint (what the device renders
+    /// with MaxBounces = 0); refraction exists on the device path only.
+    let createGlass (tint : FColor) (ior : float32) (dispersion : float32) =
+        let mutable rgb = let (FColor v) = tint in v
+        { Material = SdfMaterial.createSolid tint; Node = Native.check (Native.ft_material_glass (Native.ctx.Value, &rgb, ior, dispersion)) }
 
 [<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
 module SdfObject =
