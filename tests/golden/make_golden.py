@@ -26,19 +26,27 @@ CASES = {
     "console_like_300_64": (lambda: syn.console_like(n=300)[0], 64, 64),
     "mixed_nested_48x40": (lambda: syn.mixed_nested()[0], 48, 40),
     "combinator_zoo_56": (lambda: syn.combinator_zoo()[0], 56, 56),
+    # EXTENSIONS (no reference counterpart at all): ambient occlusion + 4 spp; glass paths with wavelength bins
+    "ext_c2_boxes_ao8_spp4_48": (lambda: syn.config2(boxes=True)[0], 48, 48, dict(spp=4, ao_samples=8, ao_radius=0.75)),
+    "ext_c5_glass_spp4_bins4_56": (lambda: syn.config5(size=56)[0], 56, 56, dict(spp=4, spectral=4, max_bounces=4)),
 }
 
 
+def ext_params(name):
+    return CASES[name][3] if len(CASES[name]) > 3 else {}
+
+
 def render(name):
-    make, W, H = CASES[name]
+    make, W, H = CASES[name][:3]
     cam = syn.default_camera().as_array()
-    img, cnt = ob.Oracle().scene(make()).render(syn.EPSILON, syn.RAY_LENGTH, W, H, cam, nthreads=4)
-    counts = np.array([cnt[k] for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "flags")], np.int64)
+    img, cnt = ob.Oracle().scene(make()).render(syn.EPSILON, syn.RAY_LENGTH, W, H, cam, nthreads=4, **ext_params(name))
+    keys = ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "flags") + (("rays_ext",) if ext_params(name) else ())
+    counts = np.array([cnt[k] for k in keys], np.int64)
     return img, counts, np.array([W, H], np.int32)
 
 
 if __name__ == "__main__":
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         img, counts, size = render(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, counts=counts, size=size,
                             epsilon=np.float32(syn.EPSILON), length=np.float32(syn.RAY_LENGTH))

@@ -36,6 +36,8 @@ def test_oracle_reproduces_golden(name):
 def test_hip_reproduces_golden(gpu, name):
     want, counts, (W, H) = load(name)
     scene = make_golden.CASES[name][0]()
-    img, st = gpu.scene(scene).render(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), syn.default_camera())
+    ext = make_golden.ext_params(name)
+    img, st = gpu.scene(scene).render(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), syn.default_camera(), **ext)
     assert_bit_equal(img, want, name)
-    assert [st["rays_primary"], st["rays_shadow"], st["hits_primary"], st["hits_shadow"], st["flags"]] == counts.tolist()
+    got = [st["rays_primary"], st["rays_shadow"], st["hits_primary"], st["hits_shadow"], st["flags"]] + ([st["rays_ext"]] if ext else [])
+    assert got == counts.tolist()
