@@ -21,9 +21,12 @@ cases = [("C1 sphere 256^2", syn.config1()[0], 256), ("C2 union32 1024^2", syn.c
          ("console-like 1000 tori 4000^2", syn.console_like(n=1000)[0], 4000),
          ("C2 union32 4096^2", syn.config2()[0], 4096),
          ("mixed nested 1024^2", syn.mixed_nested()[0], 1024),
-         ("C3 smooth256 4096^2", syn.config3()[0], 4096), ("C4 smooth256 8192^2", syn.config3()[0], 8192)]
+         ("C3 smooth256 4096^2", syn.config3()[0], 4096), ("C4 smooth256 8192^2", syn.config3()[0], 8192),
+         # EXTENSION (BASELINE.json config 5): glass paths
+         ("C5 glass 2048^2 16spp", syn.config5()[0], 2048, dict(spp=16, spectral=16, max_bounces=4))]
 only = sys.argv[1:] 
-for name, scene, n in cases:
+for name, scene, n, *rest in cases:
+    kw = rest[0] if rest else {}
     if only and not any(o in name for o in only):
         continue
     t0 = time.perf_counter()
@@ -31,16 +34,16 @@ for name, scene, n in cases:
     t_build = time.perf_counter() - t0
     buf = torch.empty((n, n, 3), dtype=torch.float32, device="cuda")
     size = ft.ImageSize(n, n)
-    ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr()); ds.collect_stats()
+    ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr(), **kw); ds.collect_stats()
     reps = 3
     for _ in range(reps):
-        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr())
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr(), **kw)
     st = ds.collect_stats()
-    rays = (st["rays_primary"] + st["rays_shadow"]) / reps
+    rays = (st["rays_primary"] + st["rays_shadow"] + st["rays_ext"]) / reps
     ms = st["kernel_ms"] / reps
-    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam)      # first call allocates staging buffers
+    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, **kw)      # first call allocates staging buffers
     t0 = time.perf_counter()
-    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam)      # host output: includes the device->host copy
+    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, **kw)      # host output: includes the device->host copy
     t_host = time.perf_counter() - t0
     print(json.dumps({"scene": name, "kernel_ms": round(ms, 3), "Mrays/s": round(rays / ms / 1e3, 2),
                       "rays": int(rays), "evals_per_ray": round(st["sdf_evals"] / reps / rays, 2),
