@@ -185,12 +185,9 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
-    const uint64_t waves = (uint64_t)blocks * (FT_BLOCK / 64);
     // one 8x8 tile per grab: measured faster than larger chunks (lanes of a wave stay on neighbouring
     // pixels) and 2.6e5 atomics per 4096^2 frame are far below the rate one counter sustains
-    (void)waves;
-    uint64_t chunk = 64;
-    a.chunk = (uint32_t)chunk;
+    a.chunk = 64;
     a.counter = c->dCounter;
     a.stats = c->dStats;
     a.S = s->dev;

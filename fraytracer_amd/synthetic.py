@@ -217,3 +217,66 @@ def combinator_zoo(seed=11):
             random_torus(rng), random_triangle(rng)]
     lights = program_lights() + [SdfLight.point((3.0, 4.0, -6.0), (0.0, 20.0, 30.0))]
     return SdfScene(SdfObject.union(objs), BACKGROUND, lights), ImageSize(96, 96)
+
+
+def fuzz_scene(seed):
+    """A random scene for differential testing (HIP path vs oracle): random combinator trees over every primitive,
+    solid and (EXTENSION) glass materials, 0-3 lights, a random camera and random render parameters.
+    Returns (scene, camera, size, epsilon, extension kwargs)."""
+    rng = Rng(0xF00D + seed)
+    P = SdfForm.Primitive
+
+    def pick(n): return int(rng.range_01() * n) % n
+
+    def prim(spread=3.0):
+        k = pick(5)
+        c = rng.pointInBall(spread)
+        if k == 0: return P.sphere(c, rng.range(0.2, 1.2))
+        if k == 1: return P.capsule(c, c + rng.pointOnSphere(rng.range(0.3, 2.0)), rng.range(0.05, 0.5))
+        if k == 2: return P.torus(c, rng.pointOnSphere(1.0), rng.range(0.3, 1.2), rng.range(0.05, 0.3))
+        if k == 3: return P.triangle(c, c + rng.pointOnSphere(rng.range(0.4, 1.5)), c + rng.pointOnSphere(rng.range(0.4, 1.5)), rng.range(0.03, 0.3))
+        return P.box(c, (rng.range(0.1, 0.9), rng.range(0.1, 0.9), rng.range(0.1, 0.9)))
+
+    def form(depth):
+        k = pick(7) if depth > 0 else 0
+        if k <= 1: return prim()
+        if k == 2:                                              # smooth union: all spheres (fast runs) or mixed
+            n = 2 + pick(9)
+            if pick(2): return SdfForm.unionSmooth(rng.range(0.05, 0.6), [P.sphere(rng.pointInBall(2.5), rng.range(0.2, 0.9)) for _ in range(n)])
+            return SdfForm.unionSmooth(rng.range(0.05, 0.6), [form(depth - 1) for _ in range(n)])
+        if k == 3: return SdfForm.union([form(depth - 1) for _ in range(2 + pick(5))])
+        if k == 4: return SdfForm.subtract(form(depth - 1), prim(2.0))
+        if k == 5: return SdfForm.intersect([form(depth - 1)] + [P.sphere(rng.pointInBall(1.0), rng.range(2.0, 4.0)) for _ in range(1 + pick(3))])
+        return SdfForm.intersect([form(depth - 1), prim(1.5), prim(1.5)])
+
+    def material():
+        if pick(5) == 0:
+            return SdfMaterial.createGlass((rng.range(0.7, 1.0), rng.range(0.7, 1.0), rng.range(0.7, 1.0)), rng.range(1.1, 2.2), rng.range(0.0, 0.06))
+        return _material(rng)
+
+    def obj(depth):
+        k = pick(6) if depth > 0 else 0
+        if k <= 2: return SdfObject.create(material(), form(2))
+        if k == 3: return SdfObject.union([obj(depth - 1) for _ in range(2 + pick(4))])
+        if k == 4: return SdfObject.subtract(obj(depth - 1), prim(2.0))
+        return SdfObject.intersect(obj(depth - 1), [P.sphere(rng.pointInBall(1.0), rng.range(2.5, 4.5))])
+
+    top = pick(4)
+    if top == 0: root = obj(1)
+    elif top == 1: root = SdfObject.create(material(), SdfForm.unionSmooth(rng.range(0.1, 0.5), [P.sphere(rng.pointInBall(3.0), rng.range(0.2, 0.8)) for _ in range(3 + pick(40))]))
+    else: root = SdfObject.union([obj(2) for _ in range(2 + pick(14))])
+    lights = []
+    for _ in range(pick(4)):
+        if pick(2): lights.append(SdfLight.directional(rng.pointOnSphere(1.0), (rng.range(0.1, 1.0), rng.range(0.1, 1.0), rng.range(0.1, 1.0))))
+        else: lights.append(SdfLight.point(rng.pointOnSphere(rng.range(5.0, 9.0)), (rng.range(5, 40), rng.range(5, 40), rng.range(5, 40))))
+    scene = SdfScene(root, (rng.range(0.0, 0.3), rng.range(0.0, 0.3), rng.range(0.0, 0.3)), lights)
+    if pick(3) == 0: cam = default_camera()
+    else: cam = Camera.lookAt(Position=rng.pointOnSphere(rng.range(7.0, 12.0)), LookAt=rng.pointInBall(1.0), Up=(0.0, 1.0, 0.0), Lens=Lens.create(rng.range(59.0, 61.5)))
+    size = ImageSize(24 + 8 * pick(5), 24 + 8 * pick(5))
+    eps = (0.01, 0.003, 0.03)[pick(3)]
+    ext = {}
+    if pick(2):
+        spp = (1, 4)[pick(2)]
+        ext = dict(spp=spp, ao_samples=(0, 0, 3, 7)[pick(4)], ao_radius=float(rng.range(0.3, 1.5)), max_bounces=(0, 2, 4, 7)[pick(4)],
+                   spectral=(0, 1, 2, 4)[pick(4)] if spp == 4 else (0, 1)[pick(2)])
+    return scene, cam, size, eps, ext

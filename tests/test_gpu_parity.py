@@ -328,6 +328,29 @@ def test_extension_glass_full_size_properties(gpu):
     assert a.max() <= solid.max() * 2.9          # a wavelength weight is below 2.9 (ft_spectral_table(16))
 
 
+def test_differential_fuzz(gpu, oracle):
+    """random combinator trees / materials / lights / cameras / render parameters (synthetic.fuzz_scene): the HIP
+    path and the oracle agree float for float and ray for ray, or both reject the scene (tools/fuzz_parity.py
+    runs the same loop over tens of thousands of seeds; profiles/r01f_fuzz.txt)"""
+    rendered = 0
+    for seed in range(5000, 5120):
+        scene, cam, size, eps, ext = syn.fuzz_scene(seed)
+        try:
+            ds = gpu.scene(scene)
+        except ft.FrayTracerError:
+            with pytest.raises(oracle.OracleError):
+                oracle.Oracle().scene(scene)
+            continue
+        g, st = ds.render(eps, LEN, size, cam, **ext)
+        o, cnt = oracle.Oracle().scene(scene).render(eps, LEN, size.X, size.Y, cam.as_array(), **ext)
+        assert_bit_equal(g, o, f"fuzz seed {seed} {ext}")
+        for k in ("rays_primary", "rays_shadow", "rays_ext", "hits_primary", "hits_shadow", "flags"):
+            assert st[k] == cnt[k], (seed, k)
+        ds.close()
+        rendered += 1
+    assert rendered > 60
+
+
 def test_nan_distances_are_flagged_identically(gpu, oracle):
     """A degenerate capsule (From == To -> dirInv = 0/0) has a NaN distance.  The reference would spin
     forever in SdfForm.tryTrace; oracle and kernel both resolve such rays as misses and raise flag bit 0."""

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Differential fuzzing: random scenes (fraytracer_amd.synthetic.fuzz_scene) rendered by the HIP path and by the
+CPU oracle must agree float for float and ray for ray.  Usage: python tools/fuzz_parity.py [first_seed] [count]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import fraytracer_amd as ft
+from fraytracer_amd import synthetic as syn
+from oracle import binding as ob
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dev = ft.Device(0)
+bad, skipped, flagged, rays, glassy = [], 0, 0, 0, 0
+t0 = time.time()
+for seed in range(first, first + count):
+    scene, cam, size, eps, ext = syn.fuzz_scene(seed)
+    try:
+        ds = dev.scene(scene)
+    except ft.FrayTracerError as e:                  # e.g. a union cell without a candidate: rejected at build time
+        try:
+            ob.Oracle().scene(scene)
+            bad.append((seed, "device rejects, oracle accepts: " + str(e)))
+        except ob.OracleError:
+            skipped += 1
+        continue
+    g, st = ds.render(eps, syn.RAY_LENGTH, size, cam, **ext)
+    o, cnt = ob.Oracle().scene(scene).render(eps, syn.RAY_LENGTH, size.X, size.Y, cam.as_array(), nthreads=8, **ext)
+    same = np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    keys = ("rays_primary", "rays_shadow", "rays_ext", "hits_primary", "hits_shadow", "flags")
+    if not same or any(st[k] != cnt[k] for k in keys):
+        bad.append((seed, int((g.view(np.uint32) != o.view(np.uint32)).sum()), {k: (st[k], cnt[k]) for k in keys if st[k] != cnt[k]}, ext))
+    flagged += st["flags"] != 0
+    glassy += st["rays_ext"] > 0
+    rays += st["rays_primary"] + st["rays_shadow"] + st["rays_ext"]
+    ds.close()
+    if (seed - first) % 50 == 49:
+        print(f"... {seed - first + 1} scenes, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(json.dumps({"first_seed": first, "scenes": count, "rejected_by_both": skipped, "with_nan_or_cap_flags": int(flagged),
+                  "with_extension_rays": int(glassy), "rays": int(rays), "mismatching_scenes": len(bad), "mismatches": bad[:20],
+                  "seconds": round(time.time() - t0, 1)}))
+sys.exit(1 if bad else 0)
