@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfraytracer_hip.so")
+# FRAYTRACER_HIP_LIB: diagnostic builds only (tools/union_divergence.py); the product is the in-tree library
+LIB_PATH = os.environ.get("FRAYTRACER_HIP_LIB") or os.path.join(_HERE, "libfraytracer_hip.so")
 
 FT_OK, FT_ERR_INVALID, FT_ERR_NO_DEVICE, FT_ERR_HIP, FT_ERR_UNSUPPORTED, FT_ERR_EMPTY, FT_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 

@@ -248,6 +248,17 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 // argmin of SdfObject.fs:27-46 tracked in the same sweep (same grid, same tests, strict '<').
 // Per-lane candidate list; lanes of a wave are neighbouring pixels and mostly share the cell.
 // ------------------------------------------------------------------------------------------------
+#ifdef FT_UNION_PROFILE
+// diagnostic build only (make PROFILE=1): [0] loop trips summed over lanes, [1] loop trips per wave x 64,
+// [2] candidate evaluations summed over lanes, [3] candidate-evaluation blocks per wave x 64
+__device__ unsigned long long ft_union_dbg[4];
+#define FT_UDBG(k, v) atomicAdd(&ft_union_dbg[k], (unsigned long long)(v))
+#define FT_UDBG_WAVE(k) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&ft_union_dbg[k], 64ull); } while (0)
+#else
+#define FT_UDBG(k, v) do {} while (0)
+#define FT_UDBG_WAVE(k) do {} while (0)
+#endif
+
 template <bool FQ>
 __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            const float* __restrict__ sd, const uint32_t* __restrict__ sl,
@@ -278,8 +289,10 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
     // (float subtraction is monotonic): leaving the loop there gives the identical result.
     for (++i; i < end; ++i) {
         const ItemRegs cur = ld_item(items + i);
+        FT_UDBG(0, 1); FT_UDBG_WAVE(1);
         if (!(mn > cur.a.x - distanceToCenter)) break;                 // :30 false for this and all later candidates
         if (mn > ft_dist<FQ>(mk3(cur.a.y, cur.a.z, cur.a.w), p) - __uint_as_float(cur.b.x)) {   // :31 getMinDistance
+            FT_UDBG(2, 1); FT_UDBG_WAVE(3);
             const uint32_t type = cur.b.y & 15u, data = cur.b.y >> 4;
             float d; uint32_t l;
             if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
@@ -910,6 +923,14 @@ extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsig
     hipLaunchKernelGGL(ft_selftest_kernel, dim3(4096), dim3(256), 0, st, op, lo, hi, d_mismatches);
     return hipGetLastError();
 }
+#ifdef FT_UNION_PROFILE
+extern "C" hipError_t ft_debug_union_counters(unsigned long long out[4]) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 4);
+    if (e != hipSuccess) return e;
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(ft_union_dbg), zero, sizeof(zero));
+}
+#endif
 extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU) {
     if (ext) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, fastPath == 1 ? ft_trace_kernel_smooth_spheres_ext : ft_trace_kernel_ext, FT_BLOCK, ldsBytes);
     if (fastPath == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel_smooth_spheres, FT_BLOCK, ldsBytes);
