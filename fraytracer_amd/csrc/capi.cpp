@@ -167,8 +167,8 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     return FT_OK;
 }
 
-// per-lane value slots (distance + material index) followed by the staged constant-pool prefix
-size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4; }
+// per-lane value slots (distance + material index), the staged constant-pool prefix, 7 per-lane statistics words
+size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4 + (size_t)7 * FT_BLOCK * 4; }
 
 int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
     if (!c->eventPool.empty()) { a = c->eventPool.back().first; b = c->eventPool.back().second; c->eventPool.pop_back(); return FT_OK; }

@@ -429,6 +429,18 @@ __constant__ float FT_AO_DIRS[16][3] = {
     {0x1.046c0ap-3f, 0x1.a248a2p-1f, -0x1.200000p-1f}, {0x1.9bff54p-2f, -0x1.3585eap-1f, -0x1.600000p-1f},
     {-0x1.21c850p-1f, 0x1.1e0d66p-3f, -0x1.a00000p-1f}, {0x1.38c4f8p-2f, 0x1.55799ap-3f, -0x1.e00000p-1f}};
 
+extern __shared__ float ft_lds[];
+
+// Per-lane statistics live in LDS (word k * FT_BLOCK + tid behind the staged constants), not in registers:
+// seven counters would otherwise stay live across the whole SDF evaluation.  One ds_add per event.
+enum : uint32_t { FT_C_EVALS = 0, FT_C_SHADOW, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
+__device__ __forceinline__ void ft_count(uint32_t cnt, uint32_t k) {
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + cnt + k * FT_BLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ft_flag(uint32_t cnt, uint32_t bits) {
+    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(ft_lds) + cnt + FT_C_FLAGS * FT_BLOCK, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct LaneState {
     uint32_t phase, job, steps, lidx, leaf, outIdx;
     f3 o, dir;            // current ray (primary, then the shadow ray of light lidx)
@@ -442,7 +454,7 @@ struct LaneState {
     float sign;               // EXTENSION glass: +1 outside, -1 inside (the march runs on sign * Distance)
     f3 thr;                   // EXTENSION: path throughput (wavelength weight x tints)
     uint32_t bounce, seed;    // EXTENSION glass: interactions so far, per-sample hash seed
-    uint32_t cEvals, cShadow, cHitP, cHitS, cPrimary, cFlags, cExt;
+    uint32_t cnt;             // this lane's first statistics word in LDS (ft_count)
 };
 
 __device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx, f3 c) {
@@ -488,7 +500,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
                 continue;
             }
             const f3 dir = ft_normalize(s.nrm + mk3(FT_AO_DIRS[s.aoIdx][0], FT_AO_DIRS[s.aoIdx][1], FT_AO_DIRS[s.aoIdx][2]));
-            s.cExt += 1;
+            ft_count(s.cnt, FT_C_EXT);
             if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.aoOpen += 1; s.aoIdx += 1; continue; }
             s.o = s.hp; s.dir = dir; s.len = a.aoRadius; s.steps = 0;
             s.phase = PH_AO;
@@ -529,7 +541,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
                     s.len = sqrtf(distance2);
                     s.lint = lc / distance2;                           // :40
                 }
-                s.steps = 0; s.cShadow += 1;
+                s.steps = 0; ft_count(s.cnt, FT_C_SHADOW);
                 s.phase = PH_SHADOW;
                 continue;
             }
@@ -572,7 +584,7 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
         }
     }
     if (EXT) { s.sign = 1.0f; s.bounce = 0; }
-    s.steps = 0; s.cPrimary += 1;
+    s.steps = 0; ft_count(s.cnt, FT_C_PRIMARY);
     s.phase = PH_MARCH;
     settle<EXT>(a, s);
 }
@@ -611,7 +623,7 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
         const float u = (float)(ft_glass_hash(s.seed, s.bounce) >> 8) * (1.0f / 16777216.0f);
         reflect = u < reflectance;
     }
-    s.cExt += 1;
+    ft_count(s.cnt, FT_C_EXT);
     if (reflect) {
         s.dir = ft_normalize(D + N * (2.0f * cosi));                   // Light.fs:56
         s.o = s.hp + N * (2.0f * s.eps);
@@ -632,8 +644,6 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return x;
 }
 
-extern __shared__ float ft_lds[];
-
 template <int VARIANT, bool EXT>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -650,7 +660,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
     s.o = s.dir = s.hp = s.nrm = s.lacc = s.lint = mk3(0, 0, 0);
     s.len = 0; s.eps = 0; s.lcos = 0;
-    s.cEvals = s.cShadow = s.cHitP = s.cHitS = s.cPrimary = s.cFlags = s.cExt = 0;
+    s.cnt = 2u * a.S.nSlots * FT_BLOCK + a.S.nStage + tid;
+    for (uint32_t k = 0; k < FT_C_COUNT; ++k) reinterpret_cast<uint32_t*>(ft_lds)[s.cnt + k * FT_BLOCK] = 0u;
     s.aoIdx = s.aoOpen = 0;
     s.sign = 1.0f; s.thr = splat3(1.0f); s.bounce = 0; s.seed = 0;
 
@@ -693,7 +704,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             float d; uint32_t leaf;
             if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
             else ft_eval(a.S, q, sd, sl, ldsC, d, leaf);
-            s.cEvals += 1;
+            ft_count(s.cnt, FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
 
             switch (s.phase) {
@@ -701,16 +712,16 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             case PH_SHADOW:
             case PH_AO: {
                 bool miss = false;
-                if (d != d) { s.cFlags |= 1u; miss = true; }           // reference would never terminate
+                if (d != d) { ft_flag(s.cnt, 1u); miss = true; }           // reference would never terminate
                 else if (d < s.eps) {                                  // SdfForm.fs:98
-                    if (s.phase == PH_MARCH) { s.cHitP += 1; s.leaf = leaf; s.phase = PH_NX; }
-                    else if (s.phase == PH_SHADOW) { s.cHitS += 1; s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
+                    if (s.phase == PH_MARCH) { ft_count(s.cnt, FT_C_HITP); s.leaf = leaf; s.phase = PH_NX; }
+                    else if (s.phase == PH_SHADOW) { ft_count(s.cnt, FT_C_HITS); s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
                     else { s.aoIdx += 1; s.phase = PH_AONEXT; }        // EXTENSION: occluded
                 } else {
                     s.o = s.o + s.dir * d;                             // Ray.move (Ray.fs:9-13)
                     s.len = s.len - d;
                     s.steps += 1;
-                    if (s.steps >= FT_STEP_CAP) { s.cFlags |= 4u; miss = true; }
+                    if (s.steps >= FT_STEP_CAP) { ft_flag(s.cnt, 4u); miss = true; }
                 }
                 if (miss) s.len = -1.0f;                               // resolved as a miss by settle()
                 break;
@@ -735,10 +746,13 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     }
 
     // ---- statistics -------------------------------------------------------------------------
-    const unsigned long long e = wave_sum(s.cEvals), sh = wave_sum(s.cShadow), hp = wave_sum(s.cHitP),
-                             hs = wave_sum(s.cHitS), pr = wave_sum(s.cPrimary), ex = wave_sum(s.cExt);
-    const unsigned long long fl = __ballot((s.cFlags & 1u) != 0) ? 1ull : 0ull;
-    const unsigned long long fc = __ballot((s.cFlags & 4u) != 0) ? 4ull : 0ull;
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(ft_lds) + s.cnt;
+    const unsigned long long e = wave_sum(cw[FT_C_EVALS * FT_BLOCK]), sh = wave_sum(cw[FT_C_SHADOW * FT_BLOCK]),
+                             hp = wave_sum(cw[FT_C_HITP * FT_BLOCK]), hs = wave_sum(cw[FT_C_HITS * FT_BLOCK]),
+                             pr = wave_sum(cw[FT_C_PRIMARY * FT_BLOCK]), ex = wave_sum(cw[FT_C_EXT * FT_BLOCK]);
+    const uint32_t cFlags = cw[FT_C_FLAGS * FT_BLOCK];
+    const unsigned long long fl = __ballot((cFlags & 1u) != 0) ? 1ull : 0ull;
+    const unsigned long long fc = __ballot((cFlags & 4u) != 0) ? 4ull : 0ull;
     if (lane == 0) {
         atomicAdd(&a.stats->sdf_evals, e);
         atomicAdd(&a.stats->rays_shadow, sh);
