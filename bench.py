@@ -6,7 +6,9 @@ at 4096x4096 (SURVEY.md §8d "C3"; 1 sample per pixel = the reference's own samp
 extension and is not what `value` is measured on).  With --gpus N the SAME frame is split into
 interleaved column stripes over N ranks (one process per GPU, launched by torch.distributed.run),
 each rank renders its stripes with the HIP kernel into HBM, and ONE RCCL gather per frame brings
-the slabs to rank 0, which de-interleaves them: total work is fixed, so scaling is "strong".
+the slabs to rank 0, which de-interleaves them: total work is fixed, so scaling is "strong".  Frames are
+pipelined (fraytracer_amd.distributed.FramePipeline): the gather of frame k runs on a side stream while
+frame k+1 renders; all K frames are complete on rank 0 when the timed region ends.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -108,17 +110,25 @@ def main():
     ds = dev.scene(scene)
     size = ft.ImageSize(W, H)
     cols = W // world
-    slab = torch.empty((cols, H, 3), dtype=torch.float32, device="cuda")
-    recv, frame = ftd.gather_buffers(slab, world, rank, force=args.force_dist)
     tiling = ftd.tiling(W, world, rank, STRIPE)
+    slab = torch.empty((cols, H, 3), dtype=torch.float32, device="cuda")
+
+    def render(dst):
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, dst.data_ptr(), **tiling)
+
+    # N > 1: frames are pipelined — stripes of frame k+1 render while the slabs of frame k travel to rank 0 in
+    # the path's ONE RCCL gather over xGMI and are de-interleaved there (side stream, double-buffered slabs)
+    pipe = ftd.FramePipeline(render, cols, H, world, rank, STRIPE, torch.device("cuda", local_rank), force=args.force_dist) if use_dist else None
 
     def step():
-        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
-        if use_dist:                              # ONE RCCL gather over xGMI + de-interleave on rank 0
-            ftd.gather_frame(slab, world, rank, STRIPE, frame=frame, recv=recv, force=args.force_dist)
+        if pipe is not None:
+            pipe.submit()
+        else:
+            render(slab)
 
     def fence():
-        if use_dist:
+        if pipe is not None:
+            pipe.drain()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +185,7 @@ def main():
                                  "(DESIGN.md section 5: ~93 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab)
+            out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab if pipe is None else pipe.frame)
             out["config"]["max_abs_delta_vs_oracle"] = check["max_abs_delta"]      # second half of the metric: 0.0 = bit-exact
             out["config"]["pixels_compared_with_oracle"] = check["pixels"]
         print(json.dumps(out), flush=True)

@@ -55,3 +55,58 @@ def gather_frame(slab, world, rank, stripe, frame=None, recv=None, group=None, f
     g = recv.view(world, cols // stripe, stripe, H, C)                                # [rank, stripe j, s, y, c]
     frame.view(cols // stripe, world, stripe, H, C).copy_(g.permute(1, 0, 2, 3, 4))
     return frame
+
+
+class FramePipeline:
+    """A stream of frames on N GPUs: every rank renders its column stripes of frame k+1 while the slabs of frame k
+    travel to rank 0 (the path's ONE collective) and are de-interleaved there.
+
+    Two slabs per rank; the render runs on the stream `render(slab)` launches on (the caller's current stream), the
+    gather and the de-interleave on a side stream.  Order kept by events:
+      render k   waits for   gather k-2 (it reuses that slab);   gather k   waits for   render k.
+    On CPU tensors (gloo tests) there are no streams and everything runs in order.
+    `render(slab)` fills this rank's slab [W/world, H, 3] asynchronously on the current stream.
+    `on_frame(k, frame)` (rank 0, optional) is called with the de-interleaved frame while the side stream is current:
+    work it enqueues consumes frame k before frame k+1 overwrites the buffer."""
+
+    def __init__(self, render, cols, H, world, rank, stripe, device, dtype=torch.float32, group=None, force=False, on_frame=None):
+        self.render, self.world, self.rank, self.stripe, self.group, self.force = render, world, rank, stripe, group, force
+        self.on_frame = on_frame
+        self.slabs = [torch.empty((cols, H, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.recv, self.frame = gather_buffers(self.slabs[0], world, rank, force)
+        self.cuda = self.slabs[0].is_cuda
+        self.k = 0
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=device)
+            self.rendered = [torch.cuda.Event() for _ in range(2)]
+            self.gathered = [None, None]
+
+    def submit(self):
+        """enqueue frame k: render on the current stream, gather behind it on the side stream"""
+        b = self.k & 1
+        slab = self.slabs[b]
+        if not self.cuda:
+            self.render(slab)
+            out = gather_frame(slab, self.world, self.rank, self.stripe, frame=self.frame, recv=self.recv, group=self.group, force=self.force)
+            if self.on_frame is not None and self.rank == 0:
+                self.on_frame(self.k, out)
+        else:
+            main = torch.cuda.current_stream()
+            if self.gathered[b] is not None:
+                main.wait_event(self.gathered[b])          # frame k-2 has left this slab
+            self.render(slab)
+            self.rendered[b].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.rendered[b])
+                out = gather_frame(slab, self.world, self.rank, self.stripe, frame=self.frame, recv=self.recv, group=self.group, force=self.force)
+                if self.on_frame is not None and self.rank == 0:
+                    self.on_frame(self.k, out)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.gathered[b] = ev
+        self.k += 1
+
+    def drain(self):
+        """make the current stream wait for every gather submitted so far"""
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)

@@ -51,6 +51,43 @@ def test_gather_reassembles_frame(world, W, stripe):
     assert q.get(timeout=5) is True
 
 
+def _pipeline_worker(rank, world, port, W, H, stripe, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cols = ftd.stripe_columns(W, world, rank, stripe)
+        frame_no = [0]
+
+        def render(slab):                                   # frame k = the column pattern + k
+            slab.copy_(torch.stack([_pixel(x, H) for x in cols]) + float(frame_no[0]))
+            frame_no[0] += 1
+
+        got = []
+        pipe = ftd.FramePipeline(render, len(cols), H, world, rank, stripe, "cpu", on_frame=lambda k, f: got.append((k, f.clone())))
+        for _ in range(5):
+            pipe.submit()
+        pipe.drain()
+        if rank == 0:
+            want = torch.stack([_pixel(x, H) for x in range(W)])
+            q.put(len(got) == 5 and all(k == i and torch.equal(f, want + float(i)) for i, (k, f) in enumerate(got)))
+        else:
+            assert not got
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_pipeline_delivers_every_frame_in_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 64, 5, 8, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) is True
+
+
 def test_stripe_mapping_partitions_the_columns():
     for world, W, S in [(1, 64, 16), (2, 64, 16), (4, 128, 8), (8, 4096, 16)]:
         seen = sorted(x for r in range(world) for x in ftd.stripe_columns(W, world, r, S))

@@ -351,6 +351,21 @@ def test_differential_fuzz(gpu, oracle):
     assert rendered > 60
 
 
+def test_frame_pipeline_over_rccl():
+    """the N > 1 host path on the one GPU of the box: 1-rank RCCL group, double-buffered slabs, gather and
+    de-interleave on a side stream (tests/rccl_rehearsal.py), and bench.py's own distributed branch"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_rehearsal.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "PIPELINE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--size", "512", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29547"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["nan_or_cap_flags"] == 0
+
+
 def test_nan_distances_are_flagged_identically(gpu, oracle):
     """A degenerate capsule (From == To -> dirInv = 0/0) has a NaN distance.  The reference would spin
     forever in SdfForm.tryTrace; oracle and kernel both resolve such rays as misses and raise flag bit 0."""
