@@ -220,7 +220,7 @@ def combinator_zoo(seed=11):
 
 
 def fuzz_scene(seed):
-    """A random scene for differential testing (HIP path vs oracle): random combinator trees over every primitive,
+    """A random scene for differential testing (HIP path against the CPU oracle): random combinator trees over every primitive,
     solid and (EXTENSION) glass materials, 0-3 lights, a random camera and random render parameters.
     Returns (scene, camera, size, epsilon, extension kwargs)."""
     rng = Rng(0xF00D + seed)
