@@ -366,6 +366,34 @@ def test_frame_pipeline_over_rccl():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["nan_or_cap_flags"] == 0
 
 
+def test_maximum_nesting_and_lds_footprint(gpu, oracle):
+    """the largest scene the kernel accepts: 48 value slots (right-nested subtract / smooth-union chain) next to a
+    2900-sphere smooth union whose constants fill the 48 KB LDS stage — 153 KB of dynamic LDS per workgroup; one
+    level deeper is FT_ERR_UNSUPPORTED, not a wrong image"""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    P = SdfForm.Primitive
+
+    def build(depth):
+        rng = syn.Rng(77)
+        blob = SdfForm.unionSmooth(0.3, [P.sphere(rng.pointInBall(3.0), rng.range(0.05, 0.2)) for _ in range(2900)])
+        f = P.sphere(rng.pointInBall(2.0), 1.0)
+        for _ in range(depth):
+            f = SdfForm.subtract(P.sphere(rng.pointInBall(1.5), rng.range(1.0, 2.0)), SdfForm.unionSmooth(0.2, [P.sphere(rng.pointInBall(2.0), 0.3), f]))
+        objs = [SdfObject.create(SdfMaterial.createSolid((0.8, 0.5, 0.3)), blob), SdfObject.create(SdfMaterial.createSolid((0.2, 0.5, 0.9)), f)]
+        return SdfScene(SdfObject.union(objs), syn.BACKGROUND, syn.program_lights())
+
+    scene = build(23)
+    ds, os_ = both(gpu, oracle, scene)
+    assert ds.info()["n_slots"] == 48
+    cam = syn.default_camera()
+    g, gst = ds.render(EPS, LEN, ft.ImageSize(40, 40), cam)
+    o, ocnt = os_.render(EPS, LEN, 40, 40, cam.as_array())
+    assert_bit_equal(g, o, "48 slots, full LDS stage")
+    check_counts(gst, ocnt)
+    with pytest.raises(ft.FrayTracerError, match="FT_MAX_SLOTS"):
+        gpu.scene(build(30))
+
+
 def test_nan_distances_are_flagged_identically(gpu, oracle):
     """A degenerate capsule (From == To -> dirInv = 0/0) has a NaN distance.  The reference would spin
     forever in SdfForm.tryTrace; oracle and kernel both resolve such rays as misses and raise flag bit 0."""
