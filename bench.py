@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="frame is size x size (default: the metric's 4096)")
     ap.add_argument("--spheres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spp4", action="store_true", help="skip the 4-samples-per-pixel (extension) timing of the same frame")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
     ap.add_argument("--cpu-columns", type=int, default=0,
@@ -143,6 +144,25 @@ def main():
     dt = time.perf_counter() - t0
     st = ds.collect_stats()                       # exact counters + HIP-event kernel time of the K timed launches
 
+    # BASELINE.json words configs[2] with "4 spp".  The reference samples once per pixel (Image.fs:28-34) and
+    # `value` is measured on that; the 4-sample EXTENSION of the same frame is timed beside it (N = 1 only).
+    spp4 = None
+    if world == 1 and pipe is None and not args.no_spp4:
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), spp=4)
+        torch.cuda.synchronize(); ds.collect_stats()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), spp=4)
+        torch.cuda.synchronize()
+        d4 = time.perf_counter() - t4
+        s4 = ds.collect_stats()
+        spp4 = {"value": round((s4["rays_primary"] + s4["rays_shadow"]) / d4 / 1e6, 3), "unit": "Mrays/s",
+                "ms_per_step": round(d4 / args.steps * 1e3, 3), "rays_per_frame": (s4["rays_primary"] + s4["rays_shadow"]) // args.steps,
+                "kernel": "ft_trace_kernel_smooth_spheres_ext + ft_resolve_kernel",
+                "note": "EXTENSION: 2x2 corner-offset samples per pixel, fixed-order resolve; sample 0 is the reference's sample"}
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr())          # the 1-spp frame again, for the oracle check
+        torch.cuda.synchronize(); ds.collect_stats()
+
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"]],
                        dtype=torch.int64, device="cuda")
@@ -184,6 +204,8 @@ def main():
                                  "flop each although a correctly rounded sqrt / reproducible exp need 5 / 11 instructions "
                                  "(DESIGN.md section 5: ~93 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
         }
+        if spp4 is not None:
+            out["config"]["same_frame_at_4_spp"] = spp4
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab if pipe is None else pipe.frame)
             out["config"]["max_abs_delta_vs_oracle"] = check["max_abs_delta"]      # second half of the metric: 0.0 = bit-exact
