@@ -100,6 +100,8 @@ SYMBOLS = {
     "ft_form_boundary": (C.c_int, [_P, _H, C.POINTER(Boundary)]),
     "ft_material_solid": (_H, [_P, _F3]),
     "ft_material_glass": (_H, [_P, _F3, C.c_float, C.c_float]),
+    "ft_form_try_trace": (C.c_int, [_P, _P, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Stats)]),
+    "ft_object_try_trace": (C.c_int, [_P, _P, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Stats)]),
     "ft_spectral_table": (C.c_int, [C.c_int32, C.c_void_p]),
     "ft_object_create": (_H, [_P, _H, _H]),
     "ft_object_union": (_H, [_P, C.POINTER(_H), C.c_int32]),

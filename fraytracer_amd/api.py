@@ -122,6 +122,41 @@ class SdfForm:
             raise ValueError("blub")                            # SdfForm.fs:71
         return forms[0] if len(forms) == 1 else Form("unionSmooth", (float(np.float32(strength)),), forms)
 
+    @staticmethod
+    def tryTrace(form, rays, device=None):
+        """SdfForm.tryTrace (SdfForm.fs:93-104) over a ray buffer on the GPU, see form_try_trace"""
+        return form_try_trace(form, rays, device)
+
+
+_trace_cache = []          # most recent first: (description, light-less scene around it); a few entries
+
+
+def _cached_scene(key, make):
+    for i, (k, scene) in enumerate(_trace_cache):
+        if k is key:
+            if i:
+                _trace_cache.insert(0, _trace_cache.pop(i))
+            return scene
+    scene = make()
+    _trace_cache.insert(0, (key, scene))
+    del _trace_cache[8:]
+    return scene
+
+
+def _object_scene(object, device):
+    """device scene holding just `object` (no lights): what the tryTrace entries need"""
+    scene = _cached_scene(object, lambda: SdfScene(object, (0.0, 0.0, 0.0), []))
+    dev = device if device is not None else Device.default(0)
+    return dev.scene(scene)
+
+
+def form_try_trace(form, rays, device=None):
+    """SdfForm.tryTrace sdf ray (SdfForm.fs:93-104) over rays [n, 8] on the GPU -> float32 [n, 10]
+    (Ray at the hit, Distance, hit flag as int32 bits); a miss (ValueNone) is a row of zeros."""
+    scene = _cached_scene(form, lambda: SdfScene(SdfObject.create(SdfMaterial.createSolid((0.0, 0.0, 0.0)), form), (0.0, 0.0, 0.0), []))
+    dev = device if device is not None else Device.default(0)
+    return dev.scene(scene).form_try_trace(rays)[0]
+
 
 class SdfMaterial:
     @staticmethod
@@ -153,6 +188,12 @@ class SdfObject:
     @staticmethod
     def intersect(object, forms):
         return Object("intersect", (), (object,) + tuple(forms))
+
+    @staticmethod
+    def tryTrace(object, rays, device=None):
+        """SdfObject.tryTrace object ray (SdfObject.fs:66-78) over rays [n, 8] on the GPU -> float32 [n, 16]
+        (Ray pulled back by epsilon, Normal, Color, hit flag as int32 bits, 0); a miss (ValueNone) is a row of zeros."""
+        return _object_scene(object, device).object_try_trace(rays)[0]
 
 
 class SdfLight:
@@ -395,6 +436,23 @@ class DeviceScene:
         check(lib.ft_trace_rays(self.device._ctx, self._scene, rays.ctypes.data_as(C.c_void_p), rays.shape[0],
                                 out.ctypes.data_as(C.c_void_p), C.byref(st)))
         return out, st.as_dict()
+
+    def _try_trace(self, fn, rays, width):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.empty((rays.shape[0], width), np.float32)
+        st = _lib.Stats()
+        check(fn(self.device._ctx, self._scene, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, st.as_dict()
+
+    def form_try_trace(self, rays):
+        """SdfForm.tryTrace scene.Object.Form over rays [n, 8] (SdfForm.fs:93-104) -> float32 [n, 10]:
+        Ray at the hit (8), Distance, hit flag (int32 bits; 0 = ValueNone, row is zeros)"""
+        return self._try_trace(lib.ft_form_try_trace, rays, 10)
+
+    def object_try_trace(self, rays):
+        """SdfObject.tryTrace scene.Object over rays [n, 8] (SdfObject.fs:66-78) -> float32 [n, 16]:
+        Ray pulled back by epsilon (8), Normal (3), Color (3), hit flag (int32 bits), 0"""
+        return self._try_trace(lib.ft_object_try_trace, rays, 16)
 
     def eval_distance(self, points):
         pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)

@@ -463,22 +463,37 @@ int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_rende
     return ft_collect_stats(c, st);
 }
 
-int ft_trace_rays(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, float* out, ft_stats* st) {
+// mode 1: SdfScene.trace (3 floats per ray); 2: SdfForm.tryTrace (10 dwords); 3: SdfObject.tryTrace (16 dwords)
+static int traceRayBuffer(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, void* out, uint32_t mode, ft_stats* st) {
     int rc = requireDevice(c); if (rc) return rc;
     if (!s || s->ctx != c || !rays || !out || n < 0) return setErr(FT_ERR_INVALID, "bad argument");
     if (n == 0) { if (st) memset(st, 0, sizeof(*st)); return FT_OK; }
     if (n >= 0xFFFF0000ll) return setErr(FT_ERR_UNSUPPORTED, "more than 2^32 rays in one call");
-    const size_t rayBytes = align256((size_t)n * sizeof(ft_ray)), outBytes = (size_t)n * 3 * sizeof(float);
+    const size_t perRay = mode == 1 ? 3 : mode == 2 ? 10 : 16;
+    const size_t rayBytes = align256((size_t)n * sizeof(ft_ray)), outBytes = (size_t)n * perRay * sizeof(float);
     if ((rc = ensureScratch(c, rayBytes + outBytes))) return rc;
     unsigned char* base = static_cast<unsigned char*>(c->scratch);
     HIP_TRY(hipMemcpyAsync(base, rays, (size_t)n * sizeof(ft_ray), hipMemcpyHostToDevice, c->stream));
     FtRenderArgs a{};
-    a.mode = 1; a.rays = reinterpret_cast<const ft_ray*>(base); a.out = reinterpret_cast<float*>(base + rayBytes);
+    a.mode = mode; a.rays = reinterpret_cast<const ft_ray*>(base); a.out = reinterpret_cast<float*>(base + rayBytes);
     a.nJobs = (uint32_t)n; a.stripeW = 1; a.stripeRanks = 1; a.tilesY = 1; a.H = 1; a.W = 1; a.nCols = 1; a.maxSize = 1.0f;
     a.spp = 1; a.sppN = 1; a.jobsPerPlane = a.nJobs; a.planePixels = a.nJobs;
+    a.ext = mode >= 2 ? 1u : 0u;                           // the tryTrace outputs exist in the EXTENSION builds of the kernel only
     if ((rc = launchTrace(c, s, a))) return rc;
     HIP_TRY(hipMemcpyAsync(out, base + rayBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
     return ft_collect_stats(c, st);
+}
+
+int ft_trace_rays(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, float* out, ft_stats* st) {
+    return traceRayBuffer(c, s, rays, n, out, 1, st);
+}
+int ft_form_try_trace(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, ft_form_trace_result* out, ft_stats* st) {
+    static_assert(sizeof(ft_form_trace_result) == 40, "layout");
+    return traceRayBuffer(c, s, rays, n, out, 2, st);
+}
+int ft_object_try_trace(ft_ctx* c, const ft_scene* s, const ft_ray* rays, int64_t n, ft_object_trace_result* out, ft_stats* st) {
+    static_assert(sizeof(ft_object_trace_result) == 64, "layout");
+    return traceRayBuffer(c, s, rays, n, out, 3, st);
 }
 
 int ft_eval_distance(ft_ctx* c, const ft_scene* s, const ft_vec3* pts, int64_t n, float* outD, int32_t* outM) {

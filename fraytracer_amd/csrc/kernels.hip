@@ -475,6 +475,17 @@ __device__ __forceinline__ uint32_t ft_glass_hash(uint32_t seed, uint32_t bounce
     return h;
 }
 
+// ft_form_try_trace / ft_object_try_trace (modes 2 / 3, EXTENSION builds of the kernel only): results are
+// 10 / 16 dwords per ray — ft_form_trace_result / ft_object_trace_result
+__device__ __forceinline__ void write_try_trace_miss(const FtRenderArgs& a, const LaneState& s) {
+    const uint32_t n = a.mode == 2u ? 10u : 16u;
+    float* o = a.out + (size_t)n * s.outIdx;
+    for (uint32_t i = 0; i < n; ++i) o[i] = 0.0f;
+}
+__device__ __forceinline__ void write_ray(float* o, f3 origin, f3 dir, float len, float eps) {
+    o[0] = origin.x; o[1] = origin.y; o[2] = origin.z; o[3] = dir.x; o[4] = dir.y; o[5] = dir.z; o[6] = len; o[7] = eps;
+}
+
 // advance a lane until it needs an SDF evaluation (or is idle): everything in SdfScene.trace that
 // is not a Distance call.
 template <bool EXT>
@@ -483,7 +494,8 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
     for (;;) {
         if (s.phase == PH_MARCH) {
             if (s.len <= 0.0f) {                                       // SdfForm.fs:94 -> SdfScene.fs:10
-                emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
+                if (EXT && a.mode >= 2u) write_try_trace_miss(a, s);   // ValueNone of the tryTrace entries
+                else emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
                 s.phase = PH_IDLE;
             }
             return;
@@ -554,7 +566,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
 
 template <bool EXT>
 __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
-    if (a.mode == 1) {                                                 // explicit ray buffer (SdfScene.trace scene ray)
+    if (a.mode >= 1) {                                                 // explicit ray buffer (SdfScene.trace scene ray; 2, 3: tryTrace entries)
         const ft_ray r = a.rays[s.job];
         s.o = mk3(r.origin.x, r.origin.y, r.origin.z);
         s.dir = mk3(r.direction.x, r.direction.y, r.direction.z);
@@ -714,7 +726,15 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 bool miss = false;
                 if (d != d) { ft_flag(s.cnt, 1u); miss = true; }           // reference would never terminate
                 else if (d < s.eps) {                                  // SdfForm.fs:98
-                    if (s.phase == PH_MARCH) { ft_count(s.cnt, FT_C_HITP); s.leaf = leaf; s.phase = PH_NX; }
+                    if (s.phase == PH_MARCH) {
+                        ft_count(s.cnt, FT_C_HITP); s.leaf = leaf; s.phase = PH_NX;
+                        if (EXT && a.mode == 2u) {                     // SdfForm.tryTrace: {Ray = ray; Distance = distance} (SdfForm.fs:98-102)
+                            float* o = a.out + 10ull * s.outIdx;
+                            write_ray(o, s.o, s.dir, s.len, s.eps);
+                            o[8] = d; reinterpret_cast<int32_t*>(o)[9] = 1;
+                            s.phase = PH_IDLE;
+                        }
+                    }
                     else if (s.phase == PH_SHADOW) { ft_count(s.cnt, FT_C_HITS); s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
                     else { s.aoIdx += 1; s.phase = PH_AONEXT; }        // EXTENSION: occluded
                 } else {
@@ -737,6 +757,14 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 s.phase = PH_LIGHTS;
                 if (EXT && a.aoSamples != 0u) { s.aoIdx = 0; s.aoOpen = 0; s.phase = PH_AONEXT; }   // EXTENSION
                 if (EXT && a.maxBounces != 0u) glass_bounce(a, s);     // EXTENSION
+                if (EXT && a.mode == 3u) {                             // SdfObject.tryTrace result (SdfObject.fs:72-77)
+                    float* o = a.out + 16ull * s.outIdx;
+                    write_ray(o, s.hp, s.dir, s.len - (-s.eps), s.eps);            // Ray.move -eps: Length - (-eps)
+                    cfp m = as_const(a.S.materials) + 3u * s.leaf;
+                    o[8] = s.nrm.x; o[9] = s.nrm.y; o[10] = s.nrm.z; o[11] = m[0]; o[12] = m[1]; o[13] = m[2];
+                    reinterpret_cast<int32_t*>(o)[14] = 1; o[15] = 0.0f;
+                    s.phase = PH_IDLE;
+                }
                 break;
             }
             default: break;

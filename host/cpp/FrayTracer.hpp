@@ -125,4 +125,26 @@ inline std::vector<float> renderScene(float epsilon, float length, ImageSize siz
 }
 }  // namespace Image
 
+// SdfObject.tryTrace / SdfForm.tryTrace (SdfObject.fs:66-78, SdfForm.fs:93-104) over a ray buffer; hit == 0 is ValueNone
+inline std::vector<ft_object_trace_result> tryTrace(const SdfObjectV& object, const std::vector<ft_ray>& rays) {
+    const float bg[3] = {0.0f, 0.0f, 0.0f};
+    ft_scene* s = nullptr;
+    check(ft_scene_create(object.ctx, object.Node, bg, nullptr, 0, &s));
+    std::vector<ft_object_trace_result> out(rays.size());
+    int rc = ft_object_try_trace(object.ctx, s, rays.data(), (int64_t)rays.size(), out.data(), nullptr);
+    ft_scene_destroy(s);
+    check(rc);
+    return out;
+}
+inline std::vector<ft_form_trace_result> formTryTrace(const SdfObjectV& object, const std::vector<ft_ray>& rays) {
+    const float bg[3] = {0.0f, 0.0f, 0.0f};
+    ft_scene* s = nullptr;
+    check(ft_scene_create(object.ctx, object.Node, bg, nullptr, 0, &s));
+    std::vector<ft_form_trace_result> out(rays.size());
+    int rc = ft_form_try_trace(object.ctx, s, rays.data(), (int64_t)rays.size(), out.data(), nullptr);
+    ft_scene_destroy(s);
+    check(rc);
+    return out;
+}
+
 }  // namespace FrayTracer

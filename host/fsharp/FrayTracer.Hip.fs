@@ -28,6 +28,14 @@ type FtStats =
     { RaysPrimary : uint64; RaysShadow : uint64; RaysExt : uint64; HitsPrimary : uint64; HitsShadow : uint64
       SdfEvals : uint64; Flags : uint64; KernelMs : float32; Reserved : float32; WaveEvals : uint64 }
 
+/// ft_form_trace_result: SdfFormTraceResult voption (Types.fs:32-37), Hit = 0 is ValueNone
+[<Struct; StructLayout(LayoutKind.Sequential)>]
+type FtFormTraceResult = { Ray : Ray; Distance : float32; Hit : int }
+
+/// ft_object_trace_result: SdfObjectTraceResult voption (Types.fs:57-65), Hit = 0 is ValueNone
+[<Struct; StructLayout(LayoutKind.Sequential)>]
+type FtObjectTraceResult = { Ray : Ray; Normal : Vector3; Color : Vector3; Hit : int; Reserved : int }
+
 module Native =
     [<Literal>]
     let Lib = "fraytracer_hip"
@@ -54,6 +62,8 @@ module Native =
     [<DllImport(Lib)>] extern int ft_light_point(nativeint ctx, Vector3& position, Vector3& rgb)
     [<DllImport(Lib)>] extern int ft_scene_create(nativeint ctx, int obj, Vector3& background, int[] lights, int n, nativeint& scene)
     [<DllImport(Lib)>] extern void ft_scene_destroy(nativeint scene)
+    [<DllImport(Lib)>] extern int ft_form_try_trace(nativeint ctx, nativeint scene, Ray[] rays, int64 n, [<Out>] FtFormTraceResult[] out, FtStats& stats)
+    [<DllImport(Lib)>] extern int ft_object_try_trace(nativeint ctx, nativeint scene, Ray[] rays, int64 n, [<Out>] FtObjectTraceResult[] out, FtStats& stats)
     [<DllImport(Lib)>] extern int ft_render(nativeint ctx, nativeint scene, Camera& camera, FtRenderParams& p, nativeint out, FtStats& stats)
 
     /// one context for the process (GPU 0); there is no CPU fallback inside the library
@@ -169,6 +179,33 @@ module SdfLight =
         let mutable rgb = let (FColor v) = color in v
         { Light = SdfLight.point position color
           Node = Native.check (Native.ft_light_point (Native.ctx.Value, &p, &rgb)) }
+
+module Trace =
+    let private withObjectScene (object : GpuObject) (f : nativeint -> 'a) =
+        let ctx = Native.ctx.Value
+        let mutable bg = Vector3.Zero
+        let mutable handle = 0n
+        Native.check (Native.ft_scene_create (ctx, object.Node, &bg, [||], 0, &handle)) |> ignore
+        try f handle finally Native.ft_scene_destroy handle
+
+    /// GPU sibling of `rays |> Array.map (SdfObject.tryTrace object)` (SdfObject.fs:66-78)
+    let objectTryTrace (object : GpuObject) (rays : Ray[]) : SdfObjectTraceResult voption[] =
+        withObjectScene object (fun scene ->
+            let out : FtObjectTraceResult[] = Array.zeroCreate rays.Length
+            let mutable stats = Unchecked.defaultof<FtStats>
+            Native.check (Native.ft_object_try_trace (Native.ctx.Value, scene, rays, int64 rays.Length, out, &stats)) |> ignore
+            out |> Array.map (fun r ->
+                if r.Hit = 0 then ValueNone
+                else ValueSome { SdfObjectTraceResult.Ray = r.Ray; Normal = r.Normal; Color = FColor r.Color }))
+
+    /// GPU sibling of `rays |> Array.map (SdfForm.tryTrace object.Form)` (SdfForm.fs:93-104)
+    let formTryTrace (object : GpuObject) (rays : Ray[]) : SdfFormTraceResult voption[] =
+        withObjectScene object (fun scene ->
+            let out : FtFormTraceResult[] = Array.zeroCreate rays.Length
+            let mutable stats = Unchecked.defaultof<FtStats>
+            Native.check (Native.ft_form_try_trace (Native.ctx.Value, scene, rays, int64 rays.Length, out, &stats)) |> ignore
+            out |> Array.map (fun r ->
+                if r.Hit = 0 then ValueNone else ValueSome { SdfFormTraceResult.Ray = r.Ray; Distance = r.Distance }))
 
 module Image =
     /// GPU sibling of `scene |> SdfScene.trace |> Image.render epsilon length imageSize camera`

@@ -48,6 +48,10 @@ typedef struct ft_ray {                                                  /* Type
     ft_vec3 origin; ft_vec3 direction; float length; float epsilon;
 } ft_ray;
 typedef struct ft_boundary { ft_vec3 center; float radius; } ft_boundary;/* Types.fs:19-24 (16 B) */
+/* SdfFormTraceResult voption (Types.fs:32-37): `hit` = 0 is ValueNone (the other fields are then 0) */
+typedef struct ft_form_trace_result { ft_ray ray; float distance; int32_t hit; } ft_form_trace_result;              /* 40 B */
+/* SdfObjectTraceResult voption (Types.fs:57-65): Ray (origin pulled back by epsilon, SdfObject.fs:73), Normal, Color */
+typedef struct ft_object_trace_result { ft_ray ray; ft_vec3 normal; ft_vec3 color; int32_t hit; int32_t reserved; } ft_object_trace_result;   /* 64 B */
 typedef struct ft_sphere { ft_vec3 center; float radius; } ft_sphere;    /* SdfForm.fs:118-123 */
 typedef struct ft_capsule { ft_vec3 from; ft_vec3 to; float radius; } ft_capsule;        /* SdfForm.fs:137-143 */
 typedef struct ft_torus { ft_vec3 center; ft_vec3 normal; float major_radius; float minor_radius; } ft_torus; /* SdfForm.fs:172-179 */
@@ -149,6 +153,13 @@ int ft_collect_stats(ft_ctx*, ft_stats* stats);
 
 /* SdfScene.trace over an explicit ray buffer (the "ray buffer" form): out_rgb is n x 3 floats. */
 int ft_trace_rays(ft_ctx*, const ft_scene*, const ft_ray* rays, int64_t n, float* out_rgb, ft_stats* stats);
+
+/* SdfForm.tryTrace scene.Object.Form ray (SdfForm.fs:93-104) over a ray buffer: the ray as it stands at the hit
+ * (Origin moved, Length reduced) and the last Distance. */
+int ft_form_try_trace(ft_ctx*, const ft_scene*, const ft_ray* rays, int64_t n, ft_form_trace_result* out, ft_stats* stats);
+/* SdfObject.tryTrace scene.Object ray (SdfObject.fs:66-78) over a ray buffer: march, normalFromRay, Ray.move -eps,
+ * material colour picked at the un-pulled hit origin. */
+int ft_object_try_trace(ft_ctx*, const ft_scene*, const ft_ray* rays, int64_t n, ft_object_trace_result* out, ft_stats* stats);
 
 /* scene.Object.Form.Distance at n points (+ index of the material the hit would pick, or
  * NULL).  Test/diagnostic entry: lets parity tests compare single SDF evaluations. */

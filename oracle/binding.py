@@ -58,6 +58,8 @@ def _load():
         "orc_scene_create": (C.c_int, [C.c_int, f3, ip, C.c_int]),
         "orc_lens_create": (C.c_float, [C.c_float]), "orc_camera_lookat": (None, [f3, f3, f3, C.c_float, f3]),
         "orc_trace_rays": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Counters)]),
+        "orc_form_try_trace": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Counters)]),
+        "orc_object_try_trace": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Counters)]),
         "orc_render": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
         "orc_render_strided": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.POINTER(Counters)]),
         "orc_render_ext": (C.c_int, [C.c_int, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(Counters)]),
@@ -173,12 +175,28 @@ class OracleScene:
                                max_bounces, spectral, out.ctypes.data_as(C.c_void_p), nthreads, C.byref(cnt)))
         return out, cnt.as_dict()
 
+    def form_try_trace(self, rays):
+        """SdfForm.tryTrace scene.Object.Form: float32 [n, 10] = Ray (8), Distance, hit (int32 bits); misses are zeros"""
+        return _try_trace(lib.orc_form_try_trace, self.handle, rays, 10)
+
+    def object_try_trace(self, rays):
+        """SdfObject.tryTrace scene.Object: float32 [n, 16] = Ray (8), Normal (3), Color (3), hit (int32 bits), 0"""
+        return _try_trace(lib.orc_object_try_trace, self.handle, rays, 16)
+
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         out = np.empty((rays.shape[0], 3), np.float32)
         cnt = Counters()
         _ck(lib.orc_trace_rays(self.handle, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p), C.byref(cnt)))
         return out, cnt.as_dict()
+
+
+def _try_trace(fn, handle, rays, width):
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    out = np.empty((rays.shape[0], width), np.float32)
+    cnt = Counters()
+    _ck(fn(handle, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+    return out, cnt.as_dict()
 
 
 def spectral_table(nw):

@@ -1084,6 +1084,48 @@ int orc_trace_rays(int scene, const float* rays, int64_t n, float* out, orc_coun
     return 0;
 }
 
+// SdfForm.tryTrace scene.Object.Form ray (SdfForm.fs:93-104): out = n x 10 dwords (Ray 8, Distance, hit as int32);
+// a miss (ValueNone) is all zeros
+int orc_form_try_trace(int scene, const float* rays, int64_t n, float* out, orc_counters* cnt) {
+    if (scene < 0 || (size_t)scene >= g_scenes.size()) return fail("bad scene handle");
+    const SdfScene& sc = g_scenes[scene];
+    tl_cnt = Counters{}; tl_flags = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* r = rays + 8 * i;
+        float* o = out + 10 * i;
+        SdfFormTraceResult res;
+        if (!Form_tryTrace(sc.Object.Form, Ray{ld3(r), ld3(r + 3), r[6], r[7]}, res)) { memset(o, 0, 40); continue; }
+        o[0] = res.ray.Origin.X; o[1] = res.ray.Origin.Y; o[2] = res.ray.Origin.Z;
+        o[3] = res.ray.Direction.X; o[4] = res.ray.Direction.Y; o[5] = res.ray.Direction.Z;
+        o[6] = res.ray.Length; o[7] = res.ray.Epsilon; o[8] = res.Distance;
+        const int32_t one = 1; memcpy(o + 9, &one, 4);
+    }
+    tl_cnt.flags = tl_flags;
+    if (cnt) memcpy(cnt, &tl_cnt, sizeof(Counters));
+    return 0;
+}
+// SdfObject.tryTrace scene.Object ray (SdfObject.fs:66-78): out = n x 16 dwords (Ray 8, Normal 3, Color 3, hit, 0)
+int orc_object_try_trace(int scene, const float* rays, int64_t n, float* out, orc_counters* cnt) {
+    if (scene < 0 || (size_t)scene >= g_scenes.size()) return fail("bad scene handle");
+    const SdfScene& sc = g_scenes[scene];
+    tl_cnt = Counters{}; tl_flags = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* r = rays + 8 * i;
+        float* o = out + 16 * i;
+        SdfObjectTraceResult res;
+        if (!Object_tryTrace(sc.Object, Ray{ld3(r), ld3(r + 3), r[6], r[7]}, res)) { memset(o, 0, 64); continue; }
+        o[0] = res.ray.Origin.X; o[1] = res.ray.Origin.Y; o[2] = res.ray.Origin.Z;
+        o[3] = res.ray.Direction.X; o[4] = res.ray.Direction.Y; o[5] = res.ray.Direction.Z;
+        o[6] = res.ray.Length; o[7] = res.ray.Epsilon;
+        o[8] = res.Normal.X; o[9] = res.Normal.Y; o[10] = res.Normal.Z;
+        o[11] = res.Color.c.X; o[12] = res.Color.c.Y; o[13] = res.Color.c.Z;
+        const int32_t one = 1; memcpy(o + 14, &one, 4); o[15] = 0.0f;
+    }
+    tl_cnt.flags = tl_flags;
+    if (cnt) memcpy(cnt, &tl_cnt, sizeof(Counters));
+    return 0;
+}
+
 // Image.render (Image.fs:26-35) over columns [x0, x1) of a W x H image; out is
 // (x1-x0) x H x 3 floats, x-major / y contiguous like FColor[X,Y] (Array2D.fs:30-38).
 // Threading mirrors Array2D.fs:32: workers pull whole x-columns.

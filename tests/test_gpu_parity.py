@@ -178,6 +178,46 @@ def test_trace_rays_matches_oracle_and_render(gpu, oracle):
     assert tuple(g[0]) == tuple(np.float32(syn.BACKGROUND))
 
 
+def test_try_trace_entries_match_oracle(gpu, oracle):
+    """ft_form_try_trace / ft_object_try_trace = SdfForm.tryTrace / SdfObject.tryTrace (SdfForm.fs:93-104,
+    SdfObject.fs:66-78) over a ray buffer: hit rays, distances, normals, colours and misses, bit for bit"""
+    rng = np.random.default_rng(13)
+    cam = syn.default_camera()
+    for scene in (syn.console_like(n=150)[0], syn.config3(n=40)[0], syn.mixed_nested()[0], syn.config5(size=64)[0]):
+        ds, os_ = both(gpu, oracle, scene)
+        W = H = 48
+        rays = [oracle.pixel_ray(cam.as_array(), W, H, x, y, EPS, LEN) for x in range(W) for y in range(H)]
+        n = 3000
+        r = np.zeros((n, 8), np.float32)
+        r[:, 0:3] = rng.uniform(-8, 8, (n, 3))
+        d = rng.normal(size=(n, 3)); r[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        r[:, 6] = rng.uniform(0, 40, n); r[:, 7] = rng.choice([0.01, 0.003, 0.05], n)
+        r[0, 6] = 0.0; r[1, 6] = -1.0
+        rays = np.concatenate([np.stack(rays), r])
+        gf, gst = ds.form_try_trace(rays)
+        of, ocnt = os_.form_try_trace(rays)
+        assert_bit_equal(gf, of, "SdfForm.tryTrace")
+        assert gst["hits_primary"] == int(gf[:, 9].view(np.int32).sum()) > 100 and gst["rays_primary"] == len(rays)
+        go, gst = ds.object_try_trace(rays)
+        oo, ocnt = os_.object_try_trace(rays)
+        assert_bit_equal(go, oo, "SdfObject.tryTrace")
+        hit = go[:, 14].view(np.int32) == 1
+        assert gst["hits_primary"] == int(hit.sum()) and gst["rays_shadow"] == 0
+        assert_bit_equal(go[hit, 3:6], rays[hit, 3:6], "direction passes through")
+        assert not go[~hit].any()
+    assert ds.form_try_trace(np.zeros((0, 8), np.float32))[0].shape == (0, 10)
+    # the mirrors of the F# functions: SdfForm.tryTrace sdf ray / SdfObject.tryTrace object ray
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial
+    form = SdfForm.unionSmooth(0.3, [SdfForm.Primitive.sphere((0.5, 0, 0), 1.0), SdfForm.Primitive.torus((0, 0, 0), (0, 1, 0), 2.0, 0.3)])
+    obj = SdfObject.create(SdfMaterial.createSolid((0.2, 0.4, 0.6)), form)
+    O = oracle.Oracle()
+    want_f, _ = O.scene(ft.SdfScene(obj, (0, 0, 0), [])).form_try_trace(rays)
+    want_o, _ = O.scene(ft.SdfScene(obj, (0, 0, 0), [])).object_try_trace(rays)
+    assert_bit_equal(SdfForm.tryTrace(form, rays, gpu), want_f, "SdfForm.tryTrace mirror")
+    assert_bit_equal(SdfObject.tryTrace(obj, rays, gpu), want_o, "SdfObject.tryTrace mirror")
+    assert_bit_equal(SdfObject.tryTrace(obj, rays[:10], gpu), want_o[:10], "cached scene")
+
+
 def test_column_tiles_concatenate_to_full_frame(gpu):
     scene, _ = syn.config2(seed=6)
     cam = syn.default_camera()

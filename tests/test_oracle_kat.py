@@ -60,6 +60,31 @@ def test_centre_pixel_two_steps_then_hit_no_lights(oracle):
     np.testing.assert_array_equal(out[0], np.array([want] * 3, F))
 
 
+def test_try_trace_entries_on_the_centre_ray(oracle):
+    # SdfForm.tryTrace (SdfForm.fs:93-104): one Ray.move by d = 9 -> Origin (0,0,-1), Length 30 - 9 = 21, Distance 0.
+    # SdfObject.tryTrace (SdfObject.fs:66-78): Ray.move -eps -> Origin z = -1 + 1*(-eps), Length 21 - (-eps);
+    # Normal = normalize of the forward differences at the pulled-back point; Color = the solid colour.
+    O = oracle.Oracle()
+    sc = O.scene(sphere_scene())
+    f, _ = sc.form_try_trace(centre_ray())
+    np.testing.assert_array_equal(f[0, :9], np.array([0, 0, -1, 0, 0, 1, 21, EPS, 0], F))
+    assert f[0, 9:10].view(np.int32)[0] == 1
+    o, _ = sc.object_try_trace(centre_ray())
+    z = F(-1) + F(1) * F(-EPS)
+    np.testing.assert_array_equal(o[0, :8], np.array([0, 0, z, 0, 0, 1, F(21) - F(-EPS), EPS], F))
+    h = F(EPS) * F(0.125)
+    dist = lambda x, y, zz: F(np.sqrt(F(F(F(x) * F(x) + F(y) * F(y)) + F(zz) * F(zz)))) - F(1)
+    g = np.array([dist(h, 0, z), dist(0, h, z), dist(0, 0, F(z + h))], F) - dist(0, 0, z)
+    n = g / F(np.sqrt(F(F(g[0] * g[0] + g[1] * g[1]) + g[2] * g[2])))
+    np.testing.assert_array_equal(o[0, 8:11], n)
+    assert abs(float(o[0, 10]) + 1.0) < 1e-3                                  # the normal faces the camera
+    np.testing.assert_array_equal(o[0, 11:14], np.array([0.8, 0.8, 0.8], F))
+    assert o[0, 14:15].view(np.int32)[0] == 1
+    # misses (ValueNone): rows of zeros
+    miss = np.array([[0, 5, -10, 0, 0, 1, LEN, EPS], [0, 0, -10, 0, 0, 1, 0.0, EPS]], F)
+    assert not sc.form_try_trace(miss)[0].any() and not sc.object_try_trace(miss)[0].any()
+
+
 def test_pulled_back_hit_point_shadows_itself(oracle):
     # SURVEY.md §7 worked example: hit origin (0,0,-1) is pulled back by eps to z = -1.00999999046;
     # a shadow ray from there sees d = 0.00999999046 < 0.01f = 0.00999999978 -> "hit" on its first
