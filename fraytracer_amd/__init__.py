@@ -5,8 +5,8 @@ This package is the host-side mirror of the reference's F# scene-composition API
 Importing it fails if the shared library has not been built; there is no CPU fallback.
 """
 from ._lib import FrayTracerError, LIB_PATH
-from .api import (FColor, SdfForm, SdfMaterial, SdfObject, SdfLight, SdfScene, Lens, Camera, ImageSize, Image,
+from .api import (FColor, SdfForm, SdfMaterial, SdfObject, SdfLight, SdfScene, Lens, Camera, ImageSize, Image, Ray,
                   Device, DeviceScene, SceneTrace, realise, render_multi)
 
 __all__ = ["FColor", "SdfForm", "SdfMaterial", "SdfObject", "SdfLight", "SdfScene", "Lens", "Camera", "ImageSize",
-           "Image", "Device", "DeviceScene", "SceneTrace", "realise", "render_multi", "FrayTracerError", "LIB_PATH"]
+           "Image", "Ray", "Device", "DeviceScene", "SceneTrace", "realise", "render_multi", "FrayTracerError", "LIB_PATH"]

@@ -127,6 +127,41 @@ class SdfForm:
         """SdfForm.tryTrace (SdfForm.fs:93-104) over a ray buffer on the GPU, see form_try_trace"""
         return form_try_trace(form, rays, device)
 
+    @staticmethod
+    def distance(form, points, device=None):
+        """sdf.Distance at points [n, 3] on the GPU -> float32 [n]"""
+        return _form_scene(form, device).eval_distance(points)[0]
+
+    @staticmethod
+    def tryDistance(form, points, device=None):
+        """SdfForm.tryDistance (SdfForm.fs:7-12): sdf.Distance where SdfBoundary.isInside (DistanceSquared(Center, p) <
+        Radius * Radius, SdfBoundary.fs:56), NaN standing for ValueNone elsewhere"""
+        F = np.float32
+        pts = np.ascontiguousarray(points, dtype=F).reshape(-1, 3)
+        ds = _form_scene(form, device)
+        b = ds.boundary()
+        d = pts - np.asarray(b[0:3], F)
+        inside = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]) < F(b[3]) * F(b[3])
+        out = ds.eval_distance(pts)[0]
+        out[~inside] = np.nan
+        return out
+
+    @staticmethod
+    def normalFromRay(form, rays, device=None):
+        """SdfForm.normalFromRay (SdfForm.fs:106-115) at the position of each ray [n, 8] -> float32 [n, 3]: forward
+        differences with h = Epsilon / 8 at Ray.get(-Epsilon), evaluated on the GPU"""
+        F = np.float32
+        r = np.ascontiguousarray(rays, dtype=F).reshape(-1, 8)
+        p = r[:, 0:3] + r[:, 3:6] * (-r[:, 7:8])
+        h = r[:, 7] * F(0.125)
+        probes = np.repeat(p[:, None, :], 4, axis=1)
+        for k in range(3):
+            probes[:, k, k] = p[:, k] + h
+        d = _form_scene(form, device).eval_distance(probes.reshape(-1, 3))[0].reshape(-1, 4)
+        g = d[:, 0:3] - d[:, 3:4]
+        with np.errstate(all="ignore"):
+            return g / np.sqrt((g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1]) + g[:, 2] * g[:, 2])[:, None]
+
 
 _trace_cache = []          # most recent first: (description, light-less scene around it); a few entries
 
@@ -150,12 +185,16 @@ def _object_scene(object, device):
     return dev.scene(scene)
 
 
+def _form_scene(form, device):
+    scene = _cached_scene(form, lambda: SdfScene(SdfObject.create(SdfMaterial.createSolid((0.0, 0.0, 0.0)), form), (0.0, 0.0, 0.0), []))
+    dev = device if device is not None else Device.default(0)
+    return dev.scene(scene)
+
+
 def form_try_trace(form, rays, device=None):
     """SdfForm.tryTrace sdf ray (SdfForm.fs:93-104) over rays [n, 8] on the GPU -> float32 [n, 10]
     (Ray at the hit, Distance, hit flag as int32 bits); a miss (ValueNone) is a row of zeros."""
-    scene = _cached_scene(form, lambda: SdfScene(SdfObject.create(SdfMaterial.createSolid((0.0, 0.0, 0.0)), form), (0.0, 0.0, 0.0), []))
-    dev = device if device is not None else Device.default(0)
-    return dev.scene(scene).form_try_trace(rays)[0]
+    return _form_scene(form, device).form_try_trace(rays)[0]
 
 
 class SdfMaterial:
@@ -368,6 +407,7 @@ class DeviceScene:
 
     def __init__(self, device, obj, bg, lights):
         self.device = device
+        self._object = obj
         p = C.c_void_p()
         hs, n = _handles(lights)
         check(lib.ft_scene_create(device._ctx, obj, _f3(bg), hs, n, C.byref(p)))
@@ -377,6 +417,10 @@ class DeviceScene:
         if self._scene:
             lib.ft_scene_destroy(self._scene)
             self._scene = None
+
+    def boundary(self):
+        """scene.Object.Form.Boundary as (cx, cy, cz, radius)"""
+        return self.device.form_boundary(self.device.object_form(self._object))
 
     def info(self):
         i = _lib.SceneInfo()
@@ -538,6 +582,19 @@ class Camera:
     def as_array(self):
         return np.frombuffer(bytes(self._c), dtype=np.float32).copy()
 
+    @staticmethod
+    def uniformPixelToRay(epsilon, length, camera, position):
+        """Camera.uniformPixelToRay (Camera.fs:44-54), host side, float32 operation by operation:
+        Direction = normalize(Forward + (px - 0.5) * RightScaled + (py - 0.5) * UpScaled) -> ray as 8 floats
+        (Origin, Direction, Length, Epsilon; Types.fs:9-17)."""
+        F = np.float32
+        a = camera.as_array()
+        pos, fw, up, rt = a[0:3], a[3:6], a[6:9], a[9:12]
+        px, py = F(position[0]), F(position[1])
+        d = (fw + F(px - F(0.5)) * rt) + F(py - F(0.5)) * up
+        d = d / np.sqrt(F(F(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))
+        return np.concatenate([pos, d, [F(length), F(epsilon)]]).astype(F)
+
     Position = property(lambda s: (s._c.position.x, s._c.position.y, s._c.position.z))
     Forward = property(lambda s: (s._c.forward.x, s._c.forward.y, s._c.forward.z))
     UpScaled = property(lambda s: (s._c.up_scaled.x, s._c.up_scaled.y, s._c.up_scaled.z))
@@ -547,6 +604,34 @@ class Camera:
 class ImageSize:
     def __init__(self, X, Y):
         self.X, self.Y = int(X), int(Y)
+
+    @staticmethod
+    def getUniformPixelPos(size):
+        """ImageSize.getUniformPixelPos (Image.fs:17-23): (x, y) -> (x / max(X, Y), y / max(X, Y)) in float32"""
+        m = np.float32(max(size.X, size.Y))
+        return lambda x, y: (np.float32(x) / m, np.float32(y) / m)
+
+
+class Ray:
+    """Ray.fs:6-15 on rays stored as 8 floats (Origin, Direction, Length, Epsilon)"""
+
+    @staticmethod
+    def get(length, ray):
+        r = np.asarray(ray, np.float32)
+        return r[0:3] + r[3:6] * np.float32(length)
+
+    @staticmethod
+    def move(length, ray):
+        r = np.asarray(ray, np.float32).copy()
+        r[0:3] = Ray.get(length, ray)
+        r[6] = r[6] - np.float32(length)
+        return r
+
+    @staticmethod
+    def setDirection(direction, ray):
+        r = np.asarray(ray, np.float32).copy()
+        r[3:6] = np.asarray(direction, np.float32)
+        return r
 
 
 class Image:

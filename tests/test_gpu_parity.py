@@ -216,6 +216,19 @@ def test_try_trace_entries_match_oracle(gpu, oracle):
     assert_bit_equal(SdfForm.tryTrace(form, rays, gpu), want_f, "SdfForm.tryTrace mirror")
     assert_bit_equal(SdfObject.tryTrace(obj, rays, gpu), want_o, "SdfObject.tryTrace mirror")
     assert_bit_equal(SdfObject.tryTrace(obj, rays[:10], gpu), want_o[:10], "cached scene")
+    # SdfForm.normalFromRay at the hit rays = the Normal of SdfObject.tryTrace; tryDistance = Distance inside the boundary
+    hit = want_f[:, 9].view(np.int32) == 1
+    assert_bit_equal(SdfForm.normalFromRay(form, want_f[hit, :8], gpu), want_o[hit, 8:11], "SdfForm.normalFromRay mirror")
+    pts = rng.uniform(-4, 4, (2000, 3)).astype(np.float32)
+    fh = O.object_form(ft.realise(obj, O))
+    want_d = O.form_distance(fh, pts)
+    assert_bit_equal(SdfForm.distance(form, pts, gpu), want_d, "sdf.Distance mirror")
+    b = np.asarray(O.form_boundary(fh), np.float32)
+    dd = pts - b[0:3]
+    inside = ((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]) < b[3] * b[3]
+    got = SdfForm.tryDistance(form, pts, gpu)
+    assert 0 < inside.sum() < len(pts) and np.isnan(got[~inside]).all()
+    assert_bit_equal(got[inside], want_d[inside], "SdfForm.tryDistance mirror")
 
 
 def test_column_tiles_concatenate_to_full_frame(gpu):

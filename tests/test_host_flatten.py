@@ -101,3 +101,21 @@ def test_errors_are_reported_not_swallowed(host):
     with pytest.raises(ft.FrayTracerError) as e:
         host.scene(syn.config1()[0]).render(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera())
     assert e.value.code == ft._lib.FT_ERR_NO_DEVICE                                             # no CPU fallback
+
+
+def test_host_side_mirrors_of_the_small_reference_functions(oracle):
+    """ImageSize.getUniformPixelPos / Camera.uniformPixelToRay (Image.fs:17-23, Camera.fs:44-54) and Ray.get / move /
+    setDirection (Ray.fs:6-15) of the Python mirror against the oracle's restatement, bit for bit"""
+    import fraytracer_amd as ft
+    cam = syn.default_camera()
+    W, H = 96, 64
+    pos = ft.ImageSize.getUniformPixelPos(ft.ImageSize(W, H))
+    for x, y in ((0, 0), (48, 32), (95, 63), (17, 5), (80, 1)):
+        got = ft.Camera.uniformPixelToRay(0.01, 30.0, cam, pos(x, y))
+        want = oracle.pixel_ray(cam.as_array(), W, H, x, y, 0.01, 30.0)
+        assert got.tobytes() == np.asarray(want, np.float32).tobytes(), (x, y)
+    r = np.array([1, 2, 3, 0, 0.6, 0.8, 30, 0.01], np.float32)
+    moved = ft.Ray.move(2.5, r)
+    np.testing.assert_array_equal(moved, np.array([1, np.float32(2) + np.float32(0.6) * np.float32(2.5), np.float32(3) + np.float32(0.8) * np.float32(2.5), 0, 0.6, 0.8, 27.5, 0.01], np.float32))
+    np.testing.assert_array_equal(ft.Ray.get(-0.01, r), r[0:3] + r[3:6] * np.float32(-0.01))
+    np.testing.assert_array_equal(ft.Ray.setDirection((1, 0, 0), r)[3:6], [1, 0, 0])
