@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -182,6 +183,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     int perCU = 0;
     HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, ldsBytes(s), &perCU));
     perCU = std::max(1, std::min(perCU, 8));
+    if (const char* cap = getenv("FT_MAX_BLOCKS_PER_CU")) { const int v = atoi(cap); if (v > 0) perCU = std::min(perCU, v); }   // experiments only
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
