@@ -117,9 +117,31 @@ def main():
     def render(dst):
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, dst.data_ptr(), **tiling)
 
-    # N > 1: frames are pipelined — stripes of frame k+1 render while the slabs of frame k travel to rank 0 in
-    # the path's ONE RCCL gather over xGMI and are de-interleaved there (side stream, double-buffered slabs)
-    pipe = ftd.FramePipeline(render, cols, H, world, rank, STRIPE, torch.device("cuda", local_rank), force=args.force_dist) if use_dist else None
+    # N > 1: frames are pipelined (fraytracer_amd.distributed.FramePipeline).  Two contexts on two streams render
+    # alternate frames, so frame k+1 fills the GPU while the few long rays of frame k drain (the tail is 2 % of
+    # a whole 4096^2 frame but 20 % of an eighth of it), and the slabs of frame k travel to rank 0 in the path's
+    # ONE RCCL gather over xGMI and are de-interleaved there on a third stream.
+    pipe, lanes = None, [ds]
+    if use_dist:
+        lane_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        dev.set_stream(lane_streams[0].cuda_stream)
+        dev2 = ft.Device(local_rank)
+        dev2.set_stream(lane_streams[1].cuda_stream)
+        lanes = [ds, dev2.scene(scene)]
+
+        def lane(d):
+            return lambda dst: d.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, dst.data_ptr(), **tiling)
+
+        pipe = ftd.FramePipeline([lane(d) for d in lanes], cols, H, world, rank, STRIPE, torch.device("cuda", local_rank),
+                                 streams=lane_streams, force=args.force_dist)
+
+    def collect():
+        """exact counters + HIP-event kernel time since the last call, summed over the render lanes"""
+        tot = None
+        for d in lanes:
+            st_ = d.collect_stats()
+            tot = st_ if tot is None else {k: tot[k] + st_[k] for k in tot}
+        return tot
 
     def step():
         if pipe is not None:
@@ -136,13 +158,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ds.collect_stats()                            # drop warm-up counters / events
+    collect()                                     # drop warm-up counters / events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    st = ds.collect_stats()                       # exact counters + HIP-event kernel time of the K timed launches
+    st = collect()                                # exact counters + HIP-event kernel time of the K timed launches
 
     # BASELINE.json words configs[2] with "4 spp".  The reference samples once per pixel (Image.fs:28-34) and
     # `value` is measured on that; the 4-sample EXTENSION of the same frame is timed beside it (N = 1 only).
@@ -204,6 +226,9 @@ def main():
                                  "flop each although a correctly rounded sqrt / reproducible exp need 5 / 11 instructions "
                                  "(DESIGN.md section 5: ~93 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
         }
+        if pipe is not None:
+            out["roofline"]["launch_overlap"] = ("consecutive frames run on two streams and overlap: kernel_ms is the mean start-to-end "
+                                                 "time of a launch, not its exclusive time; frames per second come from ms_per_step")
         if spp4 is not None:
             out["config"]["same_frame_at_4_spp"] = spp4
         if not args.no_cpu_baseline and world == 1:

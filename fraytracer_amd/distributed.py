@@ -59,43 +59,54 @@ def gather_frame(slab, world, rank, stripe, frame=None, recv=None, group=None, f
 
 class FramePipeline:
     """A stream of frames on N GPUs: every rank renders its column stripes of frame k+1 while the slabs of frame k
-    travel to rank 0 (the path's ONE collective) and are de-interleaved there.
+    travel to rank 0 (the path's ONE collective) and are de-interleaved there — and, with two render lanes, while
+    the stragglers of frame k are still marching.
 
-    Two slabs per rank; the render runs on the stream `render(slab)` launches on (the caller's current stream), the
-    gather and the de-interleave on a side stream.  Order kept by events:
+    `renders` is one callable or two: `renders[i](slab)` fills this rank's slab [W/world, H, 3] asynchronously on
+    `streams[i]` (for the HIP path: a Device whose stream was set to streams[i]).  With two lanes (two contexts on
+    two streams) consecutive frames alternate between them, so frame k+1 starts filling the GPU while the longest
+    rays of frame k drain: a persistent-wave kernel ends with a tail of a few long rays (C3: mean 29, maximum > 130
+    SDF evaluations per pixel), which costs 2 % of a 4096^2 frame on one GPU but 20 % of the 1/8 share of an 8-GPU
+    run (tools/overlap_probe.py).  The gather and the de-interleave run on a side stream.  Order kept by events:
       render k   waits for   gather k-2 (it reuses that slab);   gather k   waits for   render k.
     On CPU tensors (gloo tests) there are no streams and everything runs in order.
-    `render(slab)` fills this rank's slab [W/world, H, 3] asynchronously on the current stream.
     `on_frame(k, frame)` (rank 0, optional) is called with the de-interleaved frame while the side stream is current:
     work it enqueues consumes frame k before frame k+1 overwrites the buffer."""
 
-    def __init__(self, render, cols, H, world, rank, stripe, device, dtype=torch.float32, group=None, force=False, on_frame=None):
-        self.render, self.world, self.rank, self.stripe, self.group, self.force = render, world, rank, stripe, group, force
+    def __init__(self, renders, cols, H, world, rank, stripe, device, streams=None, dtype=torch.float32, group=None,
+                 force=False, on_frame=None):
+        self.renders = list(renders) if isinstance(renders, (list, tuple)) else [renders]
+        self.world, self.rank, self.stripe, self.group, self.force = world, rank, stripe, group, force
         self.on_frame = on_frame
         self.slabs = [torch.empty((cols, H, 3), dtype=dtype, device=device) for _ in range(2)]
         self.recv, self.frame = gather_buffers(self.slabs[0], world, rank, force)
         self.cuda = self.slabs[0].is_cuda
         self.k = 0
         if self.cuda:
+            self.streams = list(streams) if streams is not None else [torch.cuda.current_stream(device)] * len(self.renders)
+            if len(self.streams) != len(self.renders):
+                raise ValueError("one stream per render lane")
             self.side = torch.cuda.Stream(device=device)
             self.rendered = [torch.cuda.Event() for _ in range(2)]
             self.gathered = [None, None]
 
     def submit(self):
-        """enqueue frame k: render on the current stream, gather behind it on the side stream"""
+        """enqueue frame k: render on its lane's stream, gather behind it on the side stream"""
         b = self.k & 1
+        lane = b % len(self.renders)
         slab = self.slabs[b]
         if not self.cuda:
-            self.render(slab)
+            self.renders[lane](slab)
             out = gather_frame(slab, self.world, self.rank, self.stripe, frame=self.frame, recv=self.recv, group=self.group, force=self.force)
             if self.on_frame is not None and self.rank == 0:
                 self.on_frame(self.k, out)
         else:
-            main = torch.cuda.current_stream()
+            st = self.streams[lane]
             if self.gathered[b] is not None:
-                main.wait_event(self.gathered[b])          # frame k-2 has left this slab
-            self.render(slab)
-            self.rendered[b].record(main)
+                st.wait_event(self.gathered[b])            # frame k-2 has left this slab
+            with torch.cuda.stream(st):
+                self.renders[lane](slab)
+            self.rendered[b].record(st)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.rendered[b])
                 out = gather_frame(slab, self.world, self.rank, self.stripe, frame=self.frame, recv=self.recv, group=self.group, force=self.force)
@@ -107,6 +118,10 @@ class FramePipeline:
         self.k += 1
 
     def drain(self):
-        """make the current stream wait for every gather submitted so far"""
+        """make the current stream wait for every render and gather submitted so far"""
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur = torch.cuda.current_stream()
+            for st in self.streams:
+                if st != cur:
+                    cur.wait_stream(st)
+            cur.wait_stream(self.side)

@@ -20,21 +20,26 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 W = H = 256
 STRIPE = 16
-dev = ft.Device(0)
-dev.set_stream(torch.cuda.current_stream().cuda_stream)
 cam = syn.default_camera()
-scenes = [dev.scene(syn.config3(n=24 + 8 * i, size=W)[0]) for i in range(3)]      # three different frames
-want = [s.render(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), cam)[0] for s in scenes]
+descs = [syn.config3(n=24 + 8 * i, size=W)[0] for i in range(3)]                   # three different frames
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]                               # two render lanes, as bench.py uses for N > 1
+devs = [ft.Device(0), ft.Device(0)]
+for d, st in zip(devs, streams):
+    d.set_stream(st.cuda_stream)
+scenes = [[d.scene(x) for x in descs] for d in devs]
+want = [s.render(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), cam)[0] for s in scenes[0]]
 k = [0]
 
 
-def render(slab):
-    scenes[k[0] % 3].render_device(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), cam, slab.data_ptr(), **ftd.tiling(W, 1, 0, STRIPE))
-    k[0] += 1
+def lane(i):
+    def render(slab):
+        scenes[i][k[0] % 3].render_device(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), cam, slab.data_ptr(), **ftd.tiling(W, 1, 0, STRIPE))
+        k[0] += 1
+    return render
 
 
 got = []
-pipe = ftd.FramePipeline(render, W, H, 1, 0, STRIPE, torch.device("cuda", 0), force=True,
+pipe = ftd.FramePipeline([lane(0), lane(1)], W, H, 1, 0, STRIPE, torch.device("cuda", 0), streams=streams, force=True,
                          on_frame=lambda i, f: got.append(f.clone()))
 for _ in range(7):
     pipe.submit()

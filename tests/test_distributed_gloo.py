@@ -63,7 +63,8 @@ def _pipeline_worker(rank, world, port, W, H, stripe, q):
             frame_no[0] += 1
 
         got = []
-        pipe = ftd.FramePipeline(render, len(cols), H, world, rank, stripe, "cpu", on_frame=lambda k, f: got.append((k, f.clone())))
+        lanes = [render, render] if W == 64 else render      # two render lanes alternate frames
+        pipe = ftd.FramePipeline(lanes, len(cols), H, world, rank, stripe, "cpu", on_frame=lambda k, f: got.append((k, f.clone())))
         for _ in range(5):
             pipe.submit()
         pipe.drain()
