@@ -101,6 +101,16 @@ def test_errors_are_reported_not_swallowed(host):
     with pytest.raises(ft.FrayTracerError) as e:
         host.scene(syn.config1()[0]).render(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera())
     assert e.value.code == ft._lib.FT_ERR_NO_DEVICE                                             # no CPU fallback
+    # every compute entry refuses a context without a GPU: there is no CPU path anywhere in the product
+    ds = host.scene(syn.config1()[0])
+    rays = np.zeros((4, 8), np.float32)
+    for call in (lambda: ds.trace_rays(rays), lambda: ds.form_try_trace(rays), lambda: ds.object_try_trace(rays),
+                 lambda: ds.eval_distance(np.zeros((4, 3), np.float32)), lambda: ds.collect_stats(),
+                 lambda: host.math_eval(0, np.zeros(4, np.float32)), lambda: host.selftest_fastmath(),
+                 lambda: ds.render(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera(), spp=4, max_bounces=2, spectral=4)):
+        with pytest.raises(ft.FrayTracerError) as e:
+            call()
+        assert e.value.code == ft._lib.FT_ERR_NO_DEVICE
 
 
 def test_host_side_mirrors_of_the_small_reference_functions(oracle):
