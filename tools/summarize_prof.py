@@ -23,7 +23,7 @@ for f, r in rows("trace/**/*kernel_trace.csv"):
     if "ft_trace_kernel" in r.get("Kernel_Name", ""):
         print(r.get("Kernel_Name"), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "VGPR", r.get("VGPR_Count"), "SGPR", r.get("SGPR_Count"),
               "LDS", r.get("LDS_Block_Size"), "grid", r.get("Grid_Size"), "wg", r.get("Workgroup_Size"))
-for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_ta", "pmc_tcp", "pmc_tcp2"):
     acc = defaultdict(list)
     for f, r in rows(f"{name}/**/*counter_collection.csv"):
         if "ft_trace_kernel" in r.get("Kernel_Name", ""):
