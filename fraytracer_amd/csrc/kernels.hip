@@ -249,7 +249,7 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 // Per-lane candidate list; lanes of a wave are neighbouring pixels and mostly share the cell.
 // ------------------------------------------------------------------------------------------------
 #ifdef FT_UNION_PROFILE
-// diagnostic build only (make PROFILE=1): [0] loop trips summed over lanes, [1] loop trips per wave x 64,
+// diagnostic build only (`make profile`, tools/union_divergence.py): [0] loop trips summed over lanes, [1] loop trips per wave x 64,
 // [2] candidate evaluations summed over lanes, [3] candidate-evaluation blocks per wave x 64
 __device__ unsigned long long ft_union_dbg[4];
 #define FT_UDBG(k, v) atomicAdd(&ft_union_dbg[k], (unsigned long long)(v))
