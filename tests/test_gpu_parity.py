@@ -439,6 +439,7 @@ def test_bench_line_contract():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["config"]["max_abs_delta_vs_oracle"] == 0.0 and d["config"]["same_frame_at_4_spp"]["value"] > 0
+    assert d["config"]["frames_streamed_on_two_lanes"]["value"] > 0
     assert abs(d["ms_per_step"] - d["roofline"]["kernel_ms"]) < 0.35 * d["ms_per_step"]       # one kernel per step dominates
 
 
