@@ -219,11 +219,12 @@ def combinator_zoo(seed=11):
     return SdfScene(SdfObject.union(objs), BACKGROUND, lights), ImageSize(96, 96)
 
 
-def fuzz_scene(seed):
+def fuzz_scene(seed, big=False):
     """A random scene for differential testing (HIP path against the CPU oracle): random combinator trees over every primitive,
     solid and (EXTENSION) glass materials, 0-3 lights, a random camera and random render parameters.
+    `big`: unions of 60-400 objects (large grids, the device-side grid build) and larger images.
     Returns (scene, camera, size, epsilon, extension kwargs)."""
-    rng = Rng(0xF00D + seed)
+    rng = Rng((0xB16 if big else 0xF00D) + seed)
     P = SdfForm.Primitive
 
     def pick(n): return int(rng.range_01() * n) % n
@@ -262,7 +263,8 @@ def fuzz_scene(seed):
         return SdfObject.intersect(obj(depth - 1), [P.sphere(rng.pointInBall(1.0), rng.range(2.5, 4.5))])
 
     top = pick(4)
-    if top == 0: root = obj(1)
+    if big: root = SdfObject.union([SdfObject.create(material(), prim(5.0)) if pick(8) else obj(1) for _ in range(60 + pick(341))])
+    elif top == 0: root = obj(1)
     elif top == 1: root = SdfObject.create(material(), SdfForm.unionSmooth(rng.range(0.1, 0.5), [P.sphere(rng.pointInBall(3.0), rng.range(0.2, 0.8)) for _ in range(3 + pick(40))]))
     else: root = SdfObject.union([obj(2) for _ in range(2 + pick(14))])
     lights = []
@@ -272,7 +274,7 @@ def fuzz_scene(seed):
     scene = SdfScene(root, (rng.range(0.0, 0.3), rng.range(0.0, 0.3), rng.range(0.0, 0.3)), lights)
     if pick(3) == 0: cam = default_camera()
     else: cam = Camera.lookAt(Position=rng.pointOnSphere(rng.range(7.0, 12.0)), LookAt=rng.pointInBall(1.0), Up=(0.0, 1.0, 0.0), Lens=Lens.create(rng.range(59.0, 61.5)))
-    size = ImageSize(24 + 8 * pick(5), 24 + 8 * pick(5))
+    size = ImageSize(24 + 8 * pick(5), 24 + 8 * pick(5)) if not big else ImageSize(64 + 16 * pick(5), 64 + 16 * pick(5))
     eps = (0.01, 0.003, 0.03)[pick(3)]
     ext = {}
     if pick(2):

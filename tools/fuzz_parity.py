@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzzing: random scenes (fraytracer_amd.synthetic.fuzz_scene) rendered by the HIP path and by the
-CPU oracle must agree float for float and ray for ray.  Usage: python tools/fuzz_parity.py [first_seed] [count]"""
+CPU oracle must agree float for float and ray for ray.  Usage: python tools/fuzz_parity.py [first_seed] [count] [big]"""
 import json
 import os
 import sys
@@ -15,11 +15,12 @@ from oracle import binding as ob
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+big = len(sys.argv) > 3 and sys.argv[3] == "big"          # unions of 60-400 objects, larger images
 dev = ft.Device(0)
 bad, skipped, flagged, rays, glassy = [], 0, 0, 0, 0
 t0 = time.time()
 for seed in range(first, first + count):
-    scene, cam, size, eps, ext = syn.fuzz_scene(seed)
+    scene, cam, size, eps, ext = syn.fuzz_scene(seed, big)
     try:
         ds = dev.scene(scene)
     except ft.FrayTracerError as e:                  # e.g. a union cell without a candidate: rejected at build time
@@ -41,7 +42,7 @@ for seed in range(first, first + count):
     ds.close()
     if (seed - first) % 50 == 49:
         print(f"... {seed - first + 1} scenes, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(json.dumps({"first_seed": first, "scenes": count, "rejected_by_both": skipped, "with_nan_or_cap_flags": int(flagged),
+print(json.dumps({"big": big, "first_seed": first, "scenes": count, "rejected_by_both": skipped, "with_nan_or_cap_flags": int(flagged),
                   "with_extension_rays": int(glassy), "rays": int(rays), "mismatching_scenes": len(bad), "mismatches": bad[:20],
                   "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if bad else 0)
