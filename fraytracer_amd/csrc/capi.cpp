@@ -147,7 +147,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     put(oMatX, f.materialsExt.data(), f.materialsExt.size() * 4);
     FtSceneDev& d = s->dev;
     d = FtSceneDev{};
-    d.nInstr = (uint32_t)f.instr.size(); d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
+    d.nInstr = f.nMainInstr; d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
     d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ; d.nGlass = f.nGlass;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only

@@ -26,7 +26,9 @@ enum FtOp : uint32_t {
 
 enum FtPrim : uint32_t {
     FT_PR_SPHERE = 0, FT_PR_CAPSULE = 1, FT_PR_TORUS = 2, FT_PR_TRIANGLE = 3, FT_PR_BOX = 4,
-    FT_PR_SLOT = 15      // union child that is itself a combinator: value pre-evaluated in slot `data`
+    FT_PR_CALL = 14,     // union child that is a combinator WITHOUT a union inside: evaluated on demand, like a primitive,
+                         // by running the sub-program consts[data] = (first instr, end instr, result slot) (scene.cpp)
+    FT_PR_SLOT = 15      // union child that contains a union itself: value pre-evaluated in slot `data`
 };
 
 // constant-pool strides (floats) per primitive type
@@ -91,7 +93,7 @@ struct FtSceneDev {             // passed by value as kernel argument
     const FtItemRec* items;
     const FtLight* lights;
     const float* materials;     // 3 floats per material (colour, or tint of a glass)
-    uint32_t nInstr, nSlots, nLights, fastPath;
+    uint32_t nInstr, nSlots, nLights, fastPath;   // nInstr: the main program; sub-programs of FT_PR_CALL children follow it
     float bg[3];
     uint32_t nStage;            // leading floats of consts[] that every workgroup stages into LDS
     float nearR2;               // |p|^2 <= nearR2  =>  every t of the fast sphere runs is >= -87 (exp result normal)

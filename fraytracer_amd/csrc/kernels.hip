@@ -260,9 +260,9 @@ __device__ unsigned long long ft_union_dbg[4];
 #endif
 
 template <bool FQ>
-__device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
+__device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            const float* __restrict__ sd, const uint32_t* __restrict__ sl,
-                                           float& outD, uint32_t& outLeaf) {
+                                           float& outD, uint32_t& outLeaf) {   // unions without FT_PR_CALL children
     const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
     const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
     const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
@@ -304,17 +304,85 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
     outD = mn; outLeaf = leaf;
 }
 
+// the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
+// which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
+template <bool WITH_UNION, bool CALLS>
+__device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk);
+
+template <bool FQ>
+__device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
+                                           float* __restrict__ sd, uint32_t* __restrict__ sl, const float* __restrict__ ldsC,
+                                           bool fastOk, bool nearOk, float& outD, uint32_t& outLeaf) {
+    const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
+    const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
+    const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
+    const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
+    const uint32_t cell = g.cellBase + (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz);
+    cfp ctr = as_const(S.cellCenters) + 3u * cell;
+    const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
+    const uint32_t FT_CONST* cellStart = as_const(S.cellStart);
+    const FtItemRec FT_CONST* items = as_const(S.items);
+    cfp consts = as_const(S.consts);
+    uint32_t i = cellStart[cell];
+    const uint32_t end = cellStart[cell + 1];
+
+    // Items.[0] is evaluated unconditionally (SdfForm.fs:26); it is the first trip of the same loop so that the
+    // candidate evaluation — primitive switch, slot read, sub-program call — exists once in the code.
+    // The reference scans the whole list (SdfForm.fs:27).  The list is sorted by LowerBound
+    // (SdfBoundary.fs:267-268; verified NaN-free when the grid is built) and `mn` never grows, so once
+    // `mn > LowerBound - distanceToCenter` (:30) fails for one candidate it fails for every later one
+    // (float subtraction is monotonic): leaving the loop there gives the identical result.
+    float mn = 0.0f; uint32_t leaf = 0;
+    bool first = true;
+    for (; i < end; ++i) {
+        const ItemRegs cur = ld_item(items + i);
+        if (!first) {
+            FT_UDBG(0, 1); FT_UDBG_WAVE(1);
+            if (!(mn > cur.a.x - distanceToCenter)) break;             // :30 false for this and all later candidates
+            if (!(mn > ft_dist<FQ>(mk3(cur.a.y, cur.a.z, cur.a.w), p) - __uint_as_float(cur.b.x))) continue;   // :31 getMinDistance
+            FT_UDBG(2, 1); FT_UDBG_WAVE(3);
+        }
+        const uint32_t type = cur.b.y & 15u, data = cur.b.y >> 4;
+        float d; uint32_t l;
+        if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
+        else if (type == FT_PR_CALL) {
+            // lanes may need different children: run the sub-programs one at a time, each for the lanes that asked for it
+            d = 0.0f; l = 0;
+            bool pending = true;
+            for (;;) {
+                const unsigned long long m = __ballot(pending);
+                if (m == 0ull) break;
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)data, __ffsll((long long)m) - 1);
+                if (pending && data == k) {
+                    const uint32_t FT_CONST* cr = reinterpret_cast<const uint32_t FT_CONST*>(consts + k);   // (first instr, end instr, slot)
+                    const uint32_t slot = cr[2];
+                    ft_exec<false, false>(S, cr[0], cr[1], p, sd, sl, ldsC, fastOk, nearOk);
+                    d = sd[slot * FT_BLOCK]; l = sl[slot * FT_BLOCK];
+                    pending = false;
+                }
+            }
+        }
+        else { d = prim_eval_t<FQ>(type, consts + data, p); l = cur.b.z; }
+        if (first) { mn = d; leaf = l; first = false; }
+        else {
+            if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
+            mn = ft_min(mn, d);                                        // SdfForm.fs:33
+        }
+    }
+    outD = mn; outLeaf = leaf;
+}
+
 // ------------------------------------------------------------------------------------------------
 // scene SDF: wave-uniform program over per-lane value slots kept in LDS (slot s of thread t at
 // word s*FT_BLOCK + t: conflict-free).  Returns scene.Object.Form.Distance(p) and the material
 // the reference's material closure would pick at p.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
-                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
+template <bool WITH_UNION, bool CALLS>
+__device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk) {
     cfp consts = as_const(S.consts);
-    const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
-    const bool nearOk = fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
+    for (; pc < pcEnd; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
         float* dst = sd + in.dst * FT_BLOCK;
         switch (in.op) {
@@ -368,15 +436,30 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
             break;
         }
         case FT_OP_UNION: {
-            float d; uint32_t l;
-            if (fastOk && S.fastQ) eval_union<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
-            else eval_union<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
-            *dst = d; sl[in.dst * FT_BLOCK] = l;
+            if constexpr (WITH_UNION) {
+                float d; uint32_t l;
+                if constexpr (CALLS) {                                 // scenes with sub-program children (FtSceneDev.fastPath == 2)
+                    if (fastOk && S.fastQ) eval_union<true>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                    else eval_union<false>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                } else {
+                    if (fastOk && S.fastQ) eval_union_prims<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
+                    else eval_union_prims<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
+                }
+                *dst = d; sl[in.dst * FT_BLOCK] = l;
+            }
             break;
         }
         default: break;
         }
     }
+}
+
+template <bool CALLS>
+__device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
+                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
+    const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
+    const bool nearOk = fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
+    ft_exec<true, CALLS>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -715,7 +798,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             }
             float d; uint32_t leaf;
             if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
-            else ft_eval(a.S, q, sd, sl, ldsC, d, leaf);
+            else ft_eval<VARIANT == 2>(a.S, q, sd, sl, ldsC, d, leaf);
             ft_count(s.cnt, FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
 
@@ -800,6 +883,9 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_sp
 // EXTENSION builds of both (spp > 1 and / or ambient occlusion); the reference path never pays for them
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_ext(const FtRenderArgs a) { ft_trace_body<0, true>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_ext(const FtRenderArgs a) { ft_trace_body<1, true>(a); }
+// general scenes whose unions have combinator children evaluated on demand (FT_PR_CALL, FtSceneDev.fastPath == 2)
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
 
 // scene.Object.Form.Distance at explicit points (test / diagnostic entry)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
@@ -812,7 +898,7 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(con
     __syncthreads();
     for (long long i = (long long)blockIdx.x * FT_BLOCK + tid; i < n; i += (long long)gridDim.x * FT_BLOCK) {
         float d; uint32_t leaf;
-        ft_eval(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, ldsC, d, leaf);
+        ft_eval<true>(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, ldsC, d, leaf);
         outD[i] = d;
         if (outM) outM[i] = (int)leaf;
     }
@@ -934,9 +1020,12 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
     const bool ext = a->ext != 0u;
-    if (a->S.fastPath == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    const unsigned v = a->S.fastPath;                                  // 0 general, 1 lean smooth-sphere, 2 general with call children
+    if (v == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    else if (v == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    else if (v == 2 && ext) hipLaunchKernelGGL(ft_trace_kernel_calls_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    else if (v == 2) hipLaunchKernelGGL(ft_trace_kernel_calls, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (ext) hipLaunchKernelGGL(ft_trace_kernel_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
-    else if (a->S.fastPath == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     return hipGetLastError();
 }
@@ -974,7 +1063,8 @@ extern "C" hipError_t ft_debug_union_counters(unsigned long long out[4]) {
 }
 #endif
 extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU) {
-    if (ext) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, fastPath == 1 ? ft_trace_kernel_smooth_spheres_ext : ft_trace_kernel_ext, FT_BLOCK, ldsBytes);
-    if (fastPath == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel_smooth_spheres, FT_BLOCK, ldsBytes);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_trace_kernel, FT_BLOCK, ldsBytes);
+    const void* k = fastPath == 1 ? (ext ? (const void*)ft_trace_kernel_smooth_spheres_ext : (const void*)ft_trace_kernel_smooth_spheres)
+                  : fastPath == 2 ? (ext ? (const void*)ft_trace_kernel_calls_ext : (const void*)ft_trace_kernel_calls)
+                                  : (ext ? (const void*)ft_trace_kernel_ext : (const void*)ft_trace_kernel);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k, FT_BLOCK, ldsBytes);
 }

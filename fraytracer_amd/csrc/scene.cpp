@@ -497,14 +497,59 @@ struct Flattener {
         unionFastQ = unionFastQ && ok;
     }
 
+    bool formHasUnion(int h) const {
+        const HostForm& f = b.forms[h];
+        if (f.kind == HostForm::UNION) return true;
+        for (int k : f.kids) if (formHasUnion(k)) return true;
+        return false;
+    }
+    bool objectHasUnion(int h) const {
+        const HostObject& o = b.objects[h];
+        if (o.kind == HostObject::UNION) return true;
+        if (o.kind == HostObject::CREATE) return formHasUnion(o.form);
+        if (objectHasUnion(o.inner)) return true;
+        for (int f : o.forms) if (formHasUnion(f)) return true;
+        return false;
+    }
+
+    std::vector<FtInstr> subPrograms;   // bodies of the FT_PR_CALL children; appended behind the main program by flatten()
+    struct Call { uint32_t constAt, begin, end; };
+    std::vector<Call> calls;            // consts[constAt .. +2] get (first instr, end instr, slot) once the main program's length is known
+
     // union over f.kids; objs[i] >= 0 when child i is an SdfObject (material tracking), else -1.
-    // Primitive children go straight into the child table; any other child is evaluated first,
-    // unconditionally, into its own slot (evaluation has no side effects, so applying the
-    // reference's pruning tests to the stored value gives the reference's result).
+    // Primitive children go straight into the child table.  A combinator child without a union inside becomes a
+    // sub-program that the candidate loop runs on demand, exactly when the reference would call its Distance
+    // (FT_PR_CALL; all such children of one union share the slots from callBase up — a lane runs one at a time).
+    // A child that contains a union is evaluated first, unconditionally, into its own slot (evaluation has no
+    // side effects, so applying the reference's pruning tests to the stored value gives the reference's result).
     bool emitUnion(const HostForm& f, const std::vector<int>& objs, uint32_t dst) {
         const uint32_t childBase = (uint32_t)out.children.size();
         out.children.resize(childBase + f.kids.size());
         uint32_t nextSlot = dst + 1;
+        uint32_t callBase = dst + 1;
+        // which non-primitive children are evaluated up front (slot) and which on demand (call)?  A child that
+        // contains a union must be a slot.  The others become calls only when the union has more than 8 of them:
+        // the kernel variant that can call is ~15 % slower in the candidate walk itself (measured on the 1000-torus
+        // and "mixed nested" scenes), which a handful of on-demand children does not win back, while dozens or
+        // hundreds do — and could not be held in slots at all.  In such a union a child whose bounding sphere covers
+        // much of the union (wanted by most evaluations anyway) still goes up front, at most 6 of them.
+        std::vector<char> asSlot(f.kids.size(), 0);
+        size_t eligible = 0;
+        for (size_t k = 0; k < f.kids.size(); ++k) {
+            const HostForm& kf = b.forms[f.kids[k]];
+            const bool solidPrim = kf.isPrim() && (objs[k] < 0 || b.objects[objs[k]].kind == HostObject::CREATE);
+            if (!solidPrim && !(objs[k] >= 0 ? objectHasUnion(objs[k]) : formHasUnion(f.kids[k]))) ++eligible;
+        }
+        const bool useCalls = eligible > 8;
+        uint32_t bigSlots = 0;
+        for (size_t k = 0; k < f.kids.size(); ++k) {
+            const HostForm& kf = b.forms[f.kids[k]];
+            const bool solidPrim = kf.isPrim() && (objs[k] < 0 || b.objects[objs[k]].kind == HostObject::CREATE);
+            if (solidPrim) continue;
+            if (!useCalls || (objs[k] >= 0 ? objectHasUnion(objs[k]) : formHasUnion(f.kids[k]))) asSlot[k] = 1;
+            else if (bigSlots < 6 && kf.boundary.radius > 0.4f * f.boundary.radius) { asSlot[k] = 1; ++bigSlots; }
+            if (asSlot[k]) ++callBase;
+        }
         for (size_t k = 0; k < f.kids.size(); ++k) {
             const HostForm& kf = b.forms[f.kids[k]];
             noteUnionChild(kf); anyUnion = true;
@@ -515,11 +560,26 @@ struct Flattener {
             if (solidPrim) {
                 c.type = primType(kf.kind); c.data = addConsts(kf.params);
                 c.mat = ko >= 0 ? matIndex(b.objects[ko].material) : 0u;
-            } else {
-                if (nextSlot >= FT_MAX_SLOTS) return fail("union has more combinator children than FT_MAX_SLOTS value slots");
+            } else if (asSlot[k]) {
+                if (nextSlot >= FT_MAX_SLOTS) return fail("union needs more up-front value slots than FT_MAX_SLOTS");
                 if (ko >= 0 ? !emitObject(ko, nextSlot) : !emitForm(f.kids[k], nextSlot)) return false;
                 c.type = FT_PR_SLOT; c.data = nextSlot; c.mat = 0;
                 ++nextSlot;
+            } else {
+                std::vector<FtInstr> outer;
+                outer.swap(out.instr);                                  // the child's program goes to the sub-program area
+                const bool ok = ko >= 0 ? emitObject(ko, callBase) : emitForm(f.kids[k], callBase);
+                outer.swap(out.instr);                                  // out.instr = main program again, outer = the child's body
+                if (!ok) return false;
+                Call cl;
+                cl.constAt = addConsts({0.0f, 0.0f, 0.0f, 0.0f});
+                cl.begin = (uint32_t)subPrograms.size();
+                subPrograms.insert(subPrograms.end(), outer.begin(), outer.end());
+                cl.end = (uint32_t)subPrograms.size();
+                uint32_t slotBits = callBase;
+                memcpy(&out.consts[cl.constAt + 2], &slotBits, 4);
+                calls.push_back(cl);
+                c.type = FT_PR_CALL; c.data = cl.constAt; c.mat = 0;
             }
             out.children[childBase + k] = c;
         }
@@ -552,6 +612,18 @@ struct Flattener {
         out.instr.push_back(i);
         useSlot(nextSlot - 1);
         return true;
+    }
+
+    // main program | sub-programs: fix up the (first, end) instruction indices of every call record
+    void linkCalls() {
+        const uint32_t base = (uint32_t)out.instr.size();
+        out.nMainInstr = base;
+        for (const Call& cl : calls) {
+            const uint32_t first = base + cl.begin, end = base + cl.end;
+            memcpy(&out.consts[cl.constAt], &first, 4);
+            memcpy(&out.consts[cl.constAt + 1], &end, 4);
+        }
+        out.instr.insert(out.instr.end(), subPrograms.begin(), subPrograms.end());
     }
 
     bool emitObject(int h, uint32_t dst) {
@@ -591,18 +663,19 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     out = FlatScene{};
     Flattener fl(b, out, err);
     if (!fl.emitObject(object, 0)) return false;
+    fl.linkCalls();
     out.nSlots = fl.maxSlot + 1;
     out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
     out.nearR2 = (fl.stageEnd > 0 && fl.nearR > 0.0 && fl.nearR < 1e29) ? (float)(fl.nearR * fl.nearR * (1.0 - 1e-5)) : 0.0f;
     out.fastQ = (fl.anyUnion && fl.unionFastQ) ? 1u : 0u;
     // kernel variant: 1 = the program is only staged fast sphere runs + SMOOTH_FIN + SETLEAF
-    bool lean = !out.instr.empty();
+    bool lean = !out.instr.empty() && out.nMainInstr == out.instr.size();
     for (const FtInstr& in : out.instr) {
         if (in.op == FT_OP_SMOOTH_RUN) lean = lean && (in.flags & FT_FLAG_FAST) && in.dst == 0 && in.data + 4u * in.count <= out.nStage;
         else if (in.op == FT_OP_SMOOTH_FIN || in.op == FT_OP_SETLEAF) lean = lean && in.dst == 0;
         else lean = false;
     }
-    out.fastPath = lean ? 1u : 0u;
+    out.fastPath = lean ? 1u : (fl.calls.empty() ? 0u : 2u);     // kernel variant (ft_launch_trace)
     for (int i = 0; i < nLights; ++i) {
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
         out.lights.push_back(b.lights[lights[i]].dev);

@@ -85,7 +85,8 @@ struct Builder {                                              // one per ft_ctx
 };
 
 struct FlatScene {                                            // host copy of everything that goes to HBM
-    std::vector<FtInstr> instr;
+    std::vector<FtInstr> instr;                               // main program [0, nMainInstr), then the sub-programs of call children
+    uint32_t nMainInstr = 0;
     std::vector<float> consts;
     std::vector<FtGrid> grids;
     std::vector<FtChild> children;

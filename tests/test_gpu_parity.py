@@ -386,8 +386,8 @@ def test_differential_fuzz(gpu, oracle):
     path and the oracle agree float for float and ray for ray, or both reject the scene (tools/fuzz_parity.py
     runs the same loop over tens of thousands of seeds; profiles/r01f_fuzz.txt)"""
     rendered = 0
-    for seed in range(5000, 5120):
-        scene, cam, size, eps, ext = syn.fuzz_scene(seed)
+    for seed, big in [(s_, False) for s_ in range(5000, 5120)] + [(s_, True) for s_ in range(7000, 7010)]:   # big: 60-400 objects per union
+        scene, cam, size, eps, ext = syn.fuzz_scene(seed, big)
         try:
             ds = gpu.scene(scene)
         except ft.FrayTracerError:
@@ -396,7 +396,7 @@ def test_differential_fuzz(gpu, oracle):
             continue
         g, st = ds.render(eps, LEN, size, cam, **ext)
         o, cnt = oracle.Oracle().scene(scene).render(eps, LEN, size.X, size.Y, cam.as_array(), **ext)
-        assert_bit_equal(g, o, f"fuzz seed {seed} {ext}")
+        assert_bit_equal(g, o, f"fuzz seed {seed} big={big} {ext}")
         for k in ("rays_primary", "rays_shadow", "rays_ext", "hits_primary", "hits_shadow", "flags"):
             assert st[k] == cnt[k], (seed, k)
         ds.close()
@@ -469,6 +469,40 @@ def test_maximum_nesting_and_lds_footprint(gpu, oracle):
     check_counts(gst, ocnt)
     with pytest.raises(ft.FrayTracerError, match="FT_MAX_SLOTS"):
         gpu.scene(build(30))
+
+
+def test_unions_of_many_combinator_children(gpu, oracle):
+    """combinator children of a union (without a union inside) are sub-programs the candidate loop runs on demand
+    (FT_PR_CALL): hundreds of them need no slots of their own and are culled by the grid like primitives"""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    P = SdfForm.Primitive
+    rng = syn.Rng(5)
+
+    def mat(): return SdfMaterial.createSolid((rng.range_01(), rng.range_01(), rng.range_01()))
+    objs = []
+    for k in range(300):
+        c = rng.pointInBall(4.0)
+        if k % 3 == 0:
+            objs.append(SdfObject.subtract(SdfObject.create(mat(), P.sphere(c, rng.range(0.4, 0.8))), P.sphere(c + rng.pointOnSphere(0.4), 0.35)))
+        elif k % 3 == 1:
+            objs.append(SdfObject.create(mat(), SdfForm.unionSmooth(0.2, [P.sphere(c + rng.pointOnSphere(0.3), rng.range(0.2, 0.4)) for _ in range(5)])))
+        else:
+            objs.append(SdfObject.intersect(SdfObject.create(mat(), P.torus(c, rng.pointOnSphere(1.0), 0.6, 0.2)), [P.sphere(c, 0.7), P.box(c, (0.6, 0.5, 0.7))]))
+    objs += [syn.random_sphere(rng), syn.random_triangle(rng)]
+    inner = SdfObject.union([syn.random_torus(rng), SdfObject.subtract(syn.random_sphere(rng), P.sphere((0, 0, 0), 0.5))])   # a union-bearing child: slot
+    scene = SdfScene(SdfObject.union(objs + [inner]), syn.BACKGROUND, syn.program_lights())
+    ds, os_ = both(gpu, oracle, scene)
+    info = ds.info()
+    assert info["fast_path"] == 2 and info["n_slots"] <= 6 and info["n_children"] >= 303
+    cam = syn.default_camera()
+    g, gst = ds.render(EPS, LEN, ft.ImageSize(96, 96), cam)
+    o, ocnt = os_.render(EPS, LEN, 96, 96, cam.as_array())
+    assert_bit_equal(g, o, "union of 300 combinator objects")
+    check_counts(gst, ocnt)
+    assert gst["hits_primary"] > 2000
+    g, gst = ds.render(EPS, LEN, ft.ImageSize(64, 64), cam, spp=4, ao_samples=3, ao_radius=0.5)          # EXTENSION build of the variant
+    o, ocnt = os_.render(EPS, LEN, 64, 64, cam.as_array(), spp=4, ao_samples=3, ao_radius=0.5)
+    assert_bit_equal(g, o, "same, extension kernel")
 
 
 def test_nan_distances_are_flagged_identically(gpu, oracle):

@@ -89,7 +89,7 @@ def test_flattened_program_shapes(host):
 
 def test_nested_unions_use_extra_slots(host):
     i = host.scene(syn.mixed_nested()[0]).info()
-    assert i["n_grids"] == 3 and i["n_slots"] >= 3 and i["fast_path"] == 0
+    assert i["n_grids"] == 3 and i["n_slots"] >= 3 and i["fast_path"] in (0, 2)      # 2: some combinator children run on demand
 
 
 def test_errors_are_reported_not_swallowed(host):
