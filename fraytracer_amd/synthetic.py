@@ -219,6 +219,23 @@ def combinator_zoo(seed=11):
     return SdfScene(SdfObject.union(objs), BACKGROUND, lights), ImageSize(96, 96)
 
 
+def combinator_crowd(seed=5, n=300, size=1024):
+    """A union of `n` combinator objects (subtracted spheres, small smooth blobs, clipped tori): every child is a
+    sub-program the candidate walk runs on demand (ft_device.h FT_PR_CALL)."""
+    rng = Rng(seed)
+    P = SdfForm.Primitive
+    objs = []
+    for k in range(n):
+        c = rng.pointInBall(4.0)
+        if k % 3 == 0:
+            objs.append(SdfObject.subtract(SdfObject.create(_material(rng), P.sphere(c, rng.range(0.4, 0.8))), P.sphere(c + rng.pointOnSphere(0.4), 0.35)))
+        elif k % 3 == 1:
+            objs.append(SdfObject.create(_material(rng), SdfForm.unionSmooth(0.2, [P.sphere(c + rng.pointOnSphere(0.3), rng.range(0.2, 0.4)) for _ in range(5)])))
+        else:
+            objs.append(SdfObject.intersect(SdfObject.create(_material(rng), P.torus(c, rng.pointOnSphere(1.0), 0.6, 0.2)), [P.sphere(c, 0.7), P.box(c, (0.6, 0.5, 0.7))]))
+    return SdfScene(SdfObject.union(objs), BACKGROUND, program_lights()), ImageSize(size, size)
+
+
 def fuzz_scene(seed, big=False):
     """A random scene for differential testing (HIP path against the CPU oracle): random combinator trees over every primitive,
     solid and (EXTENSION) glass materials, 0-3 lights, a random camera and random render parameters.

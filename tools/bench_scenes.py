@@ -21,6 +21,7 @@ cases = [("C1 sphere 256^2", syn.config1()[0], 256), ("C2 union32 1024^2", syn.c
          ("console-like 1000 tori 4000^2", syn.console_like(n=1000)[0], 4000),
          ("C2 union32 4096^2", syn.config2()[0], 4096),
          ("mixed nested 1024^2", syn.mixed_nested()[0], 1024),
+         ("crowd of 300 combinator objects 2048^2", syn.combinator_crowd()[0], 2048),
          ("C3 smooth256 4096^2", syn.config3()[0], 4096), ("C4 smooth256 8192^2", syn.config3()[0], 8192),
          # EXTENSION (BASELINE.json config 5): glass paths
          ("C5 glass 2048^2 16spp", syn.config5()[0], 2048, dict(spp=16, spectral=16, max_bounces=4))]
