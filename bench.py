@@ -98,7 +98,18 @@ def main():
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner to stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     W = H = args.size
     if W % (STRIPE * world) != 0:
@@ -140,7 +151,7 @@ def main():
         tot = None
         for d in lanes:
             st_ = d.collect_stats()
-            tot = st_ if tot is None else {k: tot[k] + st_[k] for k in tot}
+            tot = st_ if tot is None else {k: (tot[k] if k == "lean_variant" else tot[k] + st_[k]) for k in tot}
         return tot
 
     def step():
@@ -155,6 +166,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if pipe is not None:                          # both render lanes settle (lean-kernel placement is timed per context) before anything counts
+        for d_ in lanes:
+            d_.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -250,7 +265,8 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "valu_busy_pmc": valu_busy,
-                         "kernel": "ft_trace_kernel_smooth_spheres", "kernel_ms": round(launch_s * 1e3, 3),
+                         "kernel": "ft_trace_kernel_smooth_spheres" + ("_alt" if st.get("lean_variant") == 1 else ""),
+                         "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
                                  "flop each although a correctly rounded sqrt / reproducible exp need 5 / 11 instructions "

@@ -70,7 +70,9 @@ class Stats(C.Structure):
                 ("flags", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_float), ("wave_evals", C.c_uint64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["lean_variant"] = int(self.reserved)       # diagnostic: which placement of the lean kernel the context settled on
+        return d
 
 
 class SceneInfo(C.Structure):

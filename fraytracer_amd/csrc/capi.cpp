@@ -38,6 +38,7 @@ struct ft_ctx {
     FtStatsDev* dStats = nullptr;
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
     void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
+    int leanAlt[2] = {-1, -1};                             // lean kernel placement variant per (plain, EXTENSION) build; -1 = not timed yet
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
 };
@@ -178,6 +179,43 @@ int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
     return FT_OK;
 }
 
+// The lean smooth-sphere kernel is built with two placements of its inner loop (kernels.hip FT_LOOP_PHASE): which
+// one is the fast one differs between otherwise identical MI355X boxes (59 vs 63 ms per 4096^2 frame, either way
+// round).  Once per context, on the first frame with at least 2^20 jobs, both are timed on that frame's first 2^20
+// jobs (twice each, alternating; the real launch then overwrites those pixels with the same values) and the faster
+// one is kept.  FT_LEAN_ALT=0/1 forces the choice.
+int calibrateLean(ft_ctx* c, const ft_scene* s, const FtRenderArgs& a, unsigned blocks) {
+    const int e = a.ext ? 1 : 0;
+    if (const char* f = getenv("FT_LEAN_ALT")) { c->leanAlt[e] = atoi(f) != 0; return FT_OK; }
+    FtStatsDev* tmpStats = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmpStats, sizeof(FtStatsDev)));
+    HIP_TRY(hipMemsetAsync(tmpStats, 0, sizeof(FtStatsDev), c->stream));
+    hipEvent_t e0, e1;
+    int rc = acquireEvents(c, e0, e1);
+    if (rc) { (void)hipFree(tmpStats); return rc; }
+    float ms[2] = {0.0f, 0.0f};
+    hipError_t err = hipSuccess;
+    for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
+        FtRenderArgs b = a;
+        b.leanAlt = (uint32_t)(rep & 1);
+        b.nJobs = std::min<uint32_t>(a.nJobs, 1u << 20);
+        b.stats = tmpStats;
+        if ((err = hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream)) != hipSuccess) break;
+        if ((err = hipEventRecord(e0, c->stream)) != hipSuccess) break;
+        if ((err = ft_launch_trace(&b, blocks, ldsBytes(s), c->stream)) != hipSuccess) break;
+        if ((err = hipEventRecord(e1, c->stream)) != hipSuccess) break;
+        if ((err = hipEventSynchronize(e1)) != hipSuccess) break;
+        float t = 0.0f;
+        if ((err = hipEventElapsedTime(&t, e0, e1)) != hipSuccess) break;
+        ms[rep & 1] += t;
+    }
+    c->eventPool.emplace_back(e0, e1);
+    (void)hipFree(tmpStats);
+    if (err != hipSuccess) return hipFail(err, "lean kernel calibration");
+    c->leanAlt[e] = ms[1] < ms[0] ? 1 : 0;
+    return FT_OK;
+}
+
 // launch the persistent trace kernel over nJobs jobs
 int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     int perCU = 0;
@@ -194,6 +232,11 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     a.stats = c->dStats;
     a.S = s->dev;
     a.materialsExt = s->dMaterialsExt;
+    if (s->dev.fastPath == 1) {
+        const int e = a.ext ? 1 : 0;
+        if (c->leanAlt[e] < 0 && a.nJobs >= (1u << 20) && a.mode == 0) { const int rc = calibrateLean(c, s, a, blocks); if (rc) return rc; }
+        a.leanAlt = c->leanAlt[e] > 0 ? 1u : 0u;
+    }
     HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
     hipEvent_t e0, e1;
     int rc = acquireEvents(c, e0, e1); if (rc) return rc;
@@ -449,7 +492,8 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
     if (st) {
         st->rays_primary = h.rays_primary; st->rays_shadow = h.rays_shadow; st->rays_ext = h.rays_ext;
         st->hits_primary = h.hits_primary; st->hits_shadow = h.hits_shadow; st->sdf_evals = h.sdf_evals;
-        st->flags = h.flags; st->kernel_ms = ms; st->reserved = 0.0f; st->wave_evals = h.wave_evals;
+        st->flags = h.flags; st->kernel_ms = ms; st->wave_evals = h.wave_evals;
+        st->reserved = (float)c->leanAlt[0];       // which placement of the lean kernel this context settled on (-1: not timed yet)
     }
     return FT_OK;
 }
