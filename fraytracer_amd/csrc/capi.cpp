@@ -39,6 +39,7 @@ struct ft_ctx {
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
     void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
     int leanAlt[2] = {-1, -1};                             // lean kernel placement variant per (plain, EXTENSION) build; -1 = not timed yet
+    bool leanAltFinal[2] = {false, false};                 // timed on a frame of at least 2^20 jobs (a choice made on a smaller frame is provisional)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
 };
@@ -181,12 +182,13 @@ int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
 
 // The lean smooth-sphere kernel is built with two placements of its inner loop (kernels.hip FT_LOOP_PHASE): which
 // one is the fast one differs between otherwise identical MI355X boxes (59 vs 63 ms per 4096^2 frame, either way
-// round).  Once per context, on the first frame with at least 2^20 jobs, both are timed on that frame's first 2^20
-// jobs (twice each, alternating; the real launch then overwrites those pixels with the same values) and the faster
-// one is kept.  FT_LEAN_ALT=0/1 forces the choice.
+// round).  Once per context, on the first frame with at least 2^18 jobs (512 x 512), both are timed on that frame's
+// first 2^20 jobs (alternating, twice each — four times each for frames below 2^20 jobs; the real launch then
+// overwrites those pixels with the same values) and the faster one is kept; a choice made on a frame below 2^20 jobs
+// is repeated on the first frame that has them.  FT_LEAN_ALT=0/1 forces the choice.
 int calibrateLean(ft_ctx* c, const ft_scene* s, const FtRenderArgs& a, unsigned blocks) {
     const int e = a.ext ? 1 : 0;
-    if (const char* f = getenv("FT_LEAN_ALT")) { c->leanAlt[e] = atoi(f) != 0; return FT_OK; }
+    if (const char* f = getenv("FT_LEAN_ALT")) { c->leanAlt[e] = atoi(f) != 0; c->leanAltFinal[e] = true; return FT_OK; }
     FtStatsDev* tmpStats = nullptr;
     HIP_TRY(hipMalloc((void**)&tmpStats, sizeof(FtStatsDev)));
     HIP_TRY(hipMemsetAsync(tmpStats, 0, sizeof(FtStatsDev), c->stream));
@@ -195,7 +197,8 @@ int calibrateLean(ft_ctx* c, const ft_scene* s, const FtRenderArgs& a, unsigned 
     if (rc) { (void)hipFree(tmpStats); return rc; }
     float ms[2] = {0.0f, 0.0f};
     hipError_t err = hipSuccess;
-    for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
+    const int reps = a.nJobs >= (1u << 20) ? 4 : 8;
+    for (int rep = 0; rep < reps && err == hipSuccess; ++rep) {
         FtRenderArgs b = a;
         b.leanAlt = (uint32_t)(rep & 1);
         b.nJobs = std::min<uint32_t>(a.nJobs, 1u << 20);
@@ -213,6 +216,7 @@ int calibrateLean(ft_ctx* c, const ft_scene* s, const FtRenderArgs& a, unsigned 
     (void)hipFree(tmpStats);
     if (err != hipSuccess) return hipFail(err, "lean kernel calibration");
     c->leanAlt[e] = ms[1] < ms[0] ? 1 : 0;
+    c->leanAltFinal[e] = a.nJobs >= (1u << 20);
     return FT_OK;
 }
 
@@ -234,7 +238,8 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     a.materialsExt = s->dMaterialsExt;
     if (s->dev.fastPath == 1) {
         const int e = a.ext ? 1 : 0;
-        if (c->leanAlt[e] < 0 && a.nJobs >= (1u << 20) && a.mode == 0) { const int rc = calibrateLean(c, s, a, blocks); if (rc) return rc; }
+        const bool wanted = (c->leanAlt[e] < 0 && a.nJobs >= (1u << 18)) || (!c->leanAltFinal[e] && a.nJobs >= (1u << 20));
+        if (wanted && a.mode == 0) { const int rc = calibrateLean(c, s, a, blocks); if (rc) return rc; }
         a.leanAlt = c->leanAlt[e] > 0 ? 1u : 0u;
     }
     HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
