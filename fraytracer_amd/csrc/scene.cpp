@@ -497,6 +497,20 @@ struct Flattener {
         unionFastQ = unionFastQ && ok;
     }
 
+    // rough instruction count of one evaluation of a union-free form (only used to decide slot vs call)
+    double formCost(int h) const {
+        const HostForm& f = b.forms[h];
+        switch (f.kind) {
+            case HostForm::SPHERE: return 12.0;
+            case HostForm::CAPSULE: case HostForm::BOX: return 25.0;
+            case HostForm::TORUS: return 40.0;
+            case HostForm::TRIANGLE: return 100.0;
+            default: break;
+        }
+        double c = f.kind == HostForm::SMOOTH ? 60.0 : 5.0;
+        for (int k : f.kids) c += formCost(k) + (f.kind == HostForm::SMOOTH ? 15.0 : (f.kind == HostForm::INTERSECT ? 18.0 : 0.0));
+        return c;
+    }
     bool formHasUnion(int h) const {
         const HostForm& f = b.forms[h];
         if (f.kind == HostForm::UNION) return true;
@@ -528,19 +542,25 @@ struct Flattener {
         uint32_t nextSlot = dst + 1;
         uint32_t callBase = dst + 1;
         // which non-primitive children are evaluated up front (slot) and which on demand (call)?  A child that
-        // contains a union must be a slot.  The others become calls only when the union has more than 8 of them:
-        // the kernel variant that can call is ~15 % slower in the candidate walk itself (measured on the 1000-torus
-        // and "mixed nested" scenes), which a handful of on-demand children does not win back, while dozens or
-        // hundreds do — and could not be held in slots at all.  In such a union a child whose bounding sphere covers
+        // contains a union must be a slot.  The others become calls when the union has more than 8 of them, or when
+        // the small ones among them are expensive: the kernel variant that can call is ~15 % slower in the candidate
+        // walk itself (measured on the 1000-torus and "mixed nested" scenes), which cheap on-demand children do not
+        // win back, while dozens or hundreds — which could not be held in slots at all — or costly ones do.  In such a union a child whose bounding sphere covers
         // much of the union (wanted by most evaluations anyway) still goes up front, at most 6 of them.
         std::vector<char> asSlot(f.kids.size(), 0);
         size_t eligible = 0;
+        double smallCost = 0.0;         // rough VALU cost of the eligible children that are small next to the union
         for (size_t k = 0; k < f.kids.size(); ++k) {
             const HostForm& kf = b.forms[f.kids[k]];
             const bool solidPrim = kf.isPrim() && (objs[k] < 0 || b.objects[objs[k]].kind == HostObject::CREATE);
-            if (!solidPrim && !(objs[k] >= 0 ? objectHasUnion(objs[k]) : formHasUnion(f.kids[k]))) ++eligible;
+            if (solidPrim || (objs[k] >= 0 ? objectHasUnion(objs[k]) : formHasUnion(f.kids[k]))) continue;
+            ++eligible;
+            if (!(kf.boundary.radius > 0.4f * f.boundary.radius)) smallCost += formCost(f.kids[k]);
         }
-        const bool useCalls = eligible > 8;
+        // few eligible children: calls only if evaluating the small ones up front would cost more per evaluation than
+        // the slower walk does (config 5: two glass blobs of 4 spheres, ~340 instructions -> calls, +16 %; the carved
+        // sphere of the "mixed nested" scene, ~30 -> slot)
+        const bool useCalls = eligible > 8 || smallCost >= 200.0;
         uint32_t bigSlots = 0;
         for (size_t k = 0; k < f.kids.size(); ++k) {
             const HostForm& kf = b.forms[f.kids[k]];
