@@ -75,6 +75,10 @@ class Stats(C.Structure):
         return d
 
 
+class TonemapParams(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("dither", C.c_int32), ("seed", C.c_uint32), ("bmp_order", C.c_int32)]
+
+
 class SceneInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n_instr", "n_slots", "n_consts", "n_grids", "n_children", "n_cells",
                                           "n_items", "n_lights", "n_materials", "fast_path")]
@@ -119,6 +123,10 @@ SYMBOLS = {
     "ft_render": (C.c_int, [_P, _P, C.POINTER(CameraS), C.POINTER(RenderParams), _P, C.POINTER(Stats)]),
     "ft_render_device": (C.c_int, [_P, _P, C.POINTER(CameraS), C.POINTER(RenderParams), _P]),
     "ft_collect_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "ft_tone_map_device": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(TonemapParams), _P]),
+    "ft_tone_map": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(TonemapParams), _P, C.POINTER(C.c_float)]),
+    "ft_tone_map_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(TonemapParams), _P, C.POINTER(C.c_float)]),
+    "ft_render_colors": (C.c_int, [_P, _P, C.POINTER(CameraS), C.POINTER(RenderParams), C.POINTER(TonemapParams), _P, C.POINTER(C.c_float), C.POINTER(Stats)]),
     "ft_trace_rays": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.POINTER(Stats)]),
     "ft_eval_distance": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
     "ft_scene_clone": (C.c_int, [_P, _P, C.POINTER(_P)]),

@@ -472,6 +472,19 @@ class DeviceScene:
         check(lib.ft_collect_stats(self.device._ctx, C.byref(st)))
         return st.as_dict()
 
+    def render_colors(self, epsilon, length, imageSize, camera, gamma=2.2, seed=None, bmp_order=False, **ext):
+        """Program.fs:90-100 on the device: Image.render, then Image.toColors gamma (and, with bmp_order, the scan-line
+        order of Image.toBitmap) — only 3 bytes per pixel leave the GPU.  seed None: no dithering noise (u = 0.5).
+        Returns (uint8 [X, Y, 3] R,G,B — or [Y, X, 3] B,G,R rows from the top with bmp_order —, max, stats)."""
+        p = self._params(imageSize, epsilon, length, **ext)
+        tm = _tonemap_params(gamma, seed, bmp_order)
+        out = np.empty((p.height, p.width, 3) if bmp_order else (p.width, p.height, 3), np.uint8)
+        st = _lib.Stats()
+        mx = C.c_float()
+        check(lib.ft_render_colors(self.device._ctx, self._scene, C.byref(camera._c), C.byref(p), C.byref(tm),
+                                   out.ctypes.data_as(C.c_void_p), C.byref(mx), C.byref(st)))
+        return out, float(mx.value), st.as_dict()
+
     def trace_rays(self, rays):
         """SdfScene.trace over n rays given as float32 [n, 8] (Origin, Direction, Length, Epsilon)."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
@@ -505,6 +518,23 @@ class DeviceScene:
         check(lib.ft_eval_distance(self.device._ctx, self._scene, pts.ctypes.data_as(C.c_void_p), pts.shape[0],
                                    d.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p)))
         return d, m
+
+
+def _tonemap_params(gamma, seed, bmp_order):
+    return _lib.TonemapParams(float(gamma), 0 if seed is None else 1, 0 if seed is None else int(seed) & 0xFFFFFFFF, 1 if bmp_order else 0)
+
+
+def tone_map_device(device, d_frame_ptr, X, Y, gamma=2.2, seed=None, bmp_order=False, d_out_ptr=None):
+    """Image.toColors on a frame that sits in HBM (pointer as int).  With d_out_ptr the 8-bit image stays on the device
+    (asynchronous, returns None); otherwise it is copied to the host: (uint8 array, max)."""
+    tm = _tonemap_params(gamma, seed, bmp_order)
+    if d_out_ptr is not None:
+        check(lib.ft_tone_map_device(device._ctx, C.c_void_p(d_frame_ptr), int(X), int(Y), C.byref(tm), C.c_void_p(d_out_ptr)))
+        return None
+    out = np.empty((Y, X, 3) if bmp_order else (X, Y, 3), np.uint8)
+    mx = C.c_float()
+    check(lib.ft_tone_map(device._ctx, C.c_void_p(d_frame_ptr), int(X), int(Y), C.byref(tm), out.ctypes.data_as(C.c_void_p), C.byref(mx)))
+    return out, float(mx.value)
 
 
 def spectral_table(nw):
@@ -648,3 +678,22 @@ class Image:
     @staticmethod
     def renderScene(epsilon, length, imageSize, camera, scene, device=None):
         return Image.render(epsilon, length, imageSize, camera, SdfScene.trace(scene, device))
+
+    @staticmethod
+    def toColors(gamma, rng, image, device=None, bmp_order=False):
+        """Image.toColors gamma rng image (Image.fs:37-50) on the GPU for a host FColor[X,Y] (float32 [X, Y, 3]) ->
+        uint8 [X, Y, 3].  `rng`: None = no dithering noise (u = 0.5); an int = seed of the counter-based noise (the
+        reference's shared System.Random is racy, so its low bit is not reproducible: +-1 LSB comparable)."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        X, Y = img.shape[0], img.shape[1]
+        dev = device if device is not None else Device.default(0)
+        tm = _tonemap_params(gamma, rng, bmp_order)
+        out = np.empty((Y, X, 3) if bmp_order else (X, Y, 3), np.uint8)
+        check(lib.ft_tone_map_host(dev._ctx, img.ctypes.data_as(C.c_void_p), X, Y, C.byref(tm), out.ctypes.data_as(C.c_void_p), None))
+        return out
+
+    @staticmethod
+    def saveBitmap(path, colors):
+        """Image.saveBitmap (Image.fs:88-90) for the uint8 [X, Y, 3] value of toColors: 24-bpp BMP, host side"""
+        from .postprocess import saveBitmap
+        saveBitmap(path, colors)

@@ -38,10 +38,12 @@ struct ft_ctx {
     FtStatsDev* dStats = nullptr;
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
     void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
+    void* aux = nullptr; size_t auxBytes = 0;             // tone map: [256 B: max bits | 8-bit image]
     int leanAlt[2] = {-1, -1};                             // lean kernel placement variant per (plain, EXTENSION) build; -1 = not timed yet
     bool leanAltFinal[2] = {false, false};                 // timed on a frame of at least 2^20 jobs (a choice made on a smaller frame is provisional)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect (at most FT_MAX_PENDING_EVENTS)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
+    double foldedMs = 0.0;                                 // kernel time of launches whose event pair was already recycled
 };
 
 struct ft_scene {
@@ -71,6 +73,14 @@ int ensureScratch(ft_ctx* c, size_t bytes) {
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int ensureAux(ft_ctx* c, size_t bytes) {
+    if (bytes <= c->auxBytes) return FT_OK;
+    if (c->aux) { HIP_TRY(hipFree(c->aux)); c->aux = nullptr; c->auxBytes = 0; }
+    HIP_TRY(hipMalloc(&c->aux, bytes));
+    c->auxBytes = bytes;
+    return FT_OK;
+}
 
 // Device-side per-cell grid build (kernels.hip ft_grid_build_kernel).  Declines (host build) for tiny grids,
 // more than FT_GRID_BUILD_MAX_ITEMS items or a scratch need above 512 MB.
@@ -173,6 +183,22 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 // per-lane value slots (distance + material index), the staged constant-pool prefix, 7 per-lane statistics words
 size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4 + (size_t)7 * FT_BLOCK * 4; }
 
+// A frame loop that never calls ft_collect_stats must not grow the event list: beyond this many pending pairs the
+// oldest one is folded into foldedMs (it has long completed: launches on one stream finish in order) and recycled.
+constexpr size_t FT_MAX_PENDING_EVENTS = 64;
+int foldOldestEvents(ft_ctx* c) {
+    while (c->events.size() >= FT_MAX_PENDING_EVENTS) {
+        auto p = c->events.front();
+        HIP_TRY(hipEventSynchronize(p.second));
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
+        c->foldedMs += t;
+        c->eventPool.push_back(p);
+        c->events.erase(c->events.begin());
+    }
+    return FT_OK;
+}
+
 int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
     if (!c->eventPool.empty()) { a = c->eventPool.back().first; b = c->eventPool.back().second; c->eventPool.pop_back(); return FT_OK; }
     HIP_TRY(hipEventCreate(&a));
@@ -244,7 +270,8 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     }
     HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
     hipEvent_t e0, e1;
-    int rc = acquireEvents(c, e0, e1); if (rc) return rc;
+    int rc = foldOldestEvents(c); if (rc) return rc;
+    if ((rc = acquireEvents(c, e0, e1))) return rc;
     HIP_TRY(hipEventRecord(e0, c->stream));
     HIP_TRY(ft_launch_trace(&a, blocks, ldsBytes(s), c->stream));
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -285,19 +312,21 @@ int ft_ctx_create(int device, ft_ctx** out) {
     ft_ctx* c = new ft_ctx();
     c->device = device;
     if (device >= 0) {
+        // every failure below leaves through ft_ctx_destroy, which releases whatever was created so far
+        auto fail = [&](int rc) { c->hasDevice = c->stream != nullptr || c->dCounter != nullptr || c->dStats != nullptr; ft_ctx_destroy(c); return rc; };
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
-        if (e != hipSuccess || n <= 0) { delete c; return setErr(FT_ERR_NO_DEVICE, "no HIP device visible (libfraytracer_hip has no CPU fallback)"); }
-        if (device >= n) { delete c; return setErr(FT_ERR_INVALID, "device ordinal out of range"); }
-        if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
+        if (e != hipSuccess || n <= 0) return fail(setErr(FT_ERR_NO_DEVICE, "no HIP device visible (libfraytracer_hip has no CPU fallback)"));
+        if (device >= n) return fail(setErr(FT_ERR_INVALID, "device ordinal out of range"));
+        if ((e = hipSetDevice(device)) != hipSuccess) return fail(hipFail(e, "hipSetDevice"));
         hipDeviceProp_t prop;
-        if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { delete c; return hipFail(e, "hipGetDeviceProperties"); }
+        if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(hipFail(e, "hipGetDeviceProperties"));
         c->numCUs = prop.multiProcessorCount;
-        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipFail(e, "hipStreamCreate"); }
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->stream = nullptr; return fail(hipFail(e, "hipStreamCreate")); }
         c->ownStream = true;
-        if ((e = hipMalloc((void**)&c->dCounter, 256)) != hipSuccess) { delete c; return hipFail(e, "hipMalloc"); }
-        if ((e = hipMalloc((void**)&c->dStats, sizeof(FtStatsDev))) != hipSuccess) { delete c; return hipFail(e, "hipMalloc"); }
-        if ((e = hipMemset(c->dStats, 0, sizeof(FtStatsDev))) != hipSuccess) { delete c; return hipFail(e, "hipMemset"); }
+        if ((e = hipMalloc((void**)&c->dCounter, 256)) != hipSuccess) { c->dCounter = nullptr; return fail(hipFail(e, "hipMalloc")); }
+        if ((e = hipMalloc((void**)&c->dStats, sizeof(FtStatsDev))) != hipSuccess) { c->dStats = nullptr; return fail(hipFail(e, "hipMalloc")); }
+        if ((e = hipMemset(c->dStats, 0, sizeof(FtStatsDev))) != hipSuccess) return fail(hipFail(e, "hipMemset"));
         c->hasDevice = true;
         c->filler = new DeviceGridFiller(c);
         c->builder.gridFiller = c->filler;
@@ -315,6 +344,7 @@ void ft_ctx_destroy(ft_ctx* c) {
         for (auto& p : c->eventPool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (c->scratch) (void)hipFree(c->scratch);
         if (c->planes) (void)hipFree(c->planes);
+        if (c->aux) (void)hipFree(c->aux);
         if (c->dCounter) (void)hipFree(c->dCounter);
         if (c->dStats) (void)hipFree(c->dStats);
         if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -483,7 +513,8 @@ int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const f
 int ft_collect_stats(ft_ctx* c, ft_stats* st) {
     int rc = requireDevice(c); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms = 0.0f;
+    double ms = c->foldedMs;
+    c->foldedMs = 0.0;
     for (auto& p : c->events) {
         float t = 0.0f;
         HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
@@ -497,7 +528,7 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
     if (st) {
         st->rays_primary = h.rays_primary; st->rays_shadow = h.rays_shadow; st->rays_ext = h.rays_ext;
         st->hits_primary = h.hits_primary; st->hits_shadow = h.hits_shadow; st->sdf_evals = h.sdf_evals;
-        st->flags = h.flags; st->kernel_ms = ms; st->wave_evals = h.wave_evals;
+        st->flags = h.flags; st->kernel_ms = (float)ms; st->wave_evals = h.wave_evals;
         st->reserved = (float)c->leanAlt[0];       // which placement of the lean kernel this context settled on (-1: not timed yet)
     }
     return FT_OK;
@@ -511,6 +542,63 @@ int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_rende
     if ((rc = ensureScratch(c, bytes))) return rc;
     if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    return ft_collect_stats(c, st);
+}
+
+// ---- tone map: Image.toColors / toBitmap order on the device ---------------------------------
+static int checkToneMap(const void* frame, int32_t X, int32_t Y, const ft_tonemap_params* p) {
+    if (!frame || !p || X <= 0 || Y <= 0) return setErr(FT_ERR_INVALID, "bad argument");
+    if (!(p->gamma > 0.0f)) return setErr(FT_ERR_INVALID, "gamma must be positive");
+    if ((uint64_t)X * (uint64_t)Y >= (1ull << 31)) return setErr(FT_ERR_UNSUPPORTED, "more than 2^31 pixels");
+    return FT_OK;
+}
+
+int ft_tone_map_device(ft_ctx* c, const void* d_frame, int32_t X, int32_t Y, const ft_tonemap_params* p, void* d_out) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if ((rc = checkToneMap(d_frame, X, Y, p))) return rc;
+    if (!d_out) return setErr(FT_ERR_INVALID, "null output");
+    if (reinterpret_cast<uintptr_t>(d_frame) & 15u) return setErr(FT_ERR_INVALID, "the device frame must be 16-byte aligned");
+    if ((rc = ensureAux(c, 256))) return rc;
+    const float gammaInv = 1.0f / p->gamma;                            // Image.fs:38
+    HIP_TRY(ft_launch_tonemap(static_cast<const float*>(d_frame), (uint32_t)X, (uint32_t)Y, static_cast<uint32_t*>(c->aux), gammaInv,
+                              p->dither ? 1u : 0u, p->seed, p->bmp_order != 0, static_cast<unsigned char*>(d_out), (unsigned)c->numCUs, c->stream));
+    return FT_OK;
+}
+
+int ft_tone_map(ft_ctx* c, const void* d_frame, int32_t X, int32_t Y, const ft_tonemap_params* p, uint8_t* out, float* max_out) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if ((rc = checkToneMap(d_frame, X, Y, p))) return rc;
+    if (!out) return setErr(FT_ERR_INVALID, "null output");
+    const size_t bytes = (size_t)X * Y * 3;
+    if ((rc = ensureAux(c, 256 + bytes))) return rc;
+    unsigned char* dBytes = static_cast<unsigned char*>(c->aux) + 256;
+    if ((rc = ft_tone_map_device(c, d_frame, X, Y, p, dBytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dBytes, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (max_out) HIP_TRY(hipMemcpyAsync(max_out, c->aux, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FT_OK;
+}
+
+int ft_tone_map_host(ft_ctx* c, const float* frame, int32_t X, int32_t Y, const ft_tonemap_params* p, uint8_t* out, float* max_out) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if ((rc = checkToneMap(frame, X, Y, p))) return rc;
+    const size_t bytes = (size_t)X * Y * 12;
+    if ((rc = ensureScratch(c, bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->scratch, frame, bytes, hipMemcpyHostToDevice, c->stream));
+    return ft_tone_map(c, c->scratch, X, Y, p, out, max_out);
+}
+
+int ft_render_colors(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, const ft_tonemap_params* tm,
+                     uint8_t* out, float* max_out, ft_stats* st) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!out || !tm) return setErr(FT_ERR_INVALID, "null argument");
+    if ((rc = checkParams(p))) return rc;
+    if (p->x0 != 0 || p->n_columns != p->width || p->stripe_ranks != 1)
+        return setErr(FT_ERR_INVALID, "the tone map needs the whole frame (its normalisation is the global maximum, Image.fs:40-43)");
+    const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    if ((rc = ensureScratch(c, bytes))) return rc;
+    if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
+    if ((rc = ft_tone_map(c, c->scratch, p->width, p->height, tm, out, max_out))) return rc;
     return ft_collect_stats(c, st);
 }
 
@@ -618,6 +706,7 @@ int ft_scene_info_get(const ft_scene* s, ft_scene_info* o) {
 
 int ft_scene_grid_shape(const ft_scene* s, int32_t g, float info[6], int32_t counts[3], int32_t* nCells, int32_t* nItems) {
     if (!s || g < 0 || (size_t)g >= s->flat.grids.size()) return setErr(FT_ERR_INVALID, "bad grid index");
+    if (!info || !counts) return setErr(FT_ERR_INVALID, "null output");
     const FtGrid& G = s->flat.grids[g];
     for (int i = 0; i < 3; ++i) { info[i] = G.aabbMin[i]; info[3 + i] = G.cellSizeInv[i]; counts[i] = G.count[i]; }
     const int32_t nc = G.count[0] * G.count[1] * G.count[2];
@@ -628,6 +717,7 @@ int ft_scene_grid_shape(const ft_scene* s, int32_t g, float info[6], int32_t cou
 
 int ft_scene_grid_dump(const ft_scene* s, int32_t g, uint32_t* cellStart, float* centers, float* lower, int32_t* child) {
     if (!s || g < 0 || (size_t)g >= s->flat.grids.size()) return setErr(FT_ERR_INVALID, "bad grid index");
+    if (!cellStart || !centers || !lower || !child) return setErr(FT_ERR_INVALID, "null output");
     const ft::FlatScene& f = s->flat;
     const FtGrid& G = f.grids[g];
     const uint32_t nc = (uint32_t)(G.count[0] * G.count[1] * G.count[2]);

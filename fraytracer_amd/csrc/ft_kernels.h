@@ -53,6 +53,9 @@ hipError_t ft_launch_grid_build(const FtGridBuildArgs* a, hipStream_t st);
 hipError_t ft_launch_grid_compact(const FtItem* tmp, const uint32_t* cellStart, uint32_t ncells, uint32_t n, FtItem* items, hipStream_t st);
 #define FT_GRID_BUILD_MAX_ITEMS 4096
 hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st);
+// Image.toColors (+ toBitmap order) on the device: max pass + map pass on one stream; maxBits = 4 bytes of device scratch
+hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_t* maxBits, float gammaInv, uint32_t dither, uint32_t seed,
+                             int bmpOrder, unsigned char* out, unsigned numCUs, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
 hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus

@@ -137,3 +137,67 @@ FT_HD float ft_log(float x) {
     if (x == INFINITY) return x;
     return (float)ft_log_f64((double)x);
 }
+
+// ---------------------------------------------------------------------------------------------
+// pow for the tone map (FColor.gammaInverse, FColor.fs:50-55: MathF.Pow per channel).  MathF.Pow is
+// platform libm in .NET; this is a fixed algorithm from IEEE double + - * / only: exp(g * log(x)) in
+// double (fdlibm e_log.c / e_exp.c structure), rounded to float once.  Its double-precision error
+// (~1e-14 relative) is far below half a float ulp, so it returns the correctly rounded powf except
+// within ~1e-7 relative probability of a rounding boundary.
+// ---------------------------------------------------------------------------------------------
+FT_HD double ft_exp_f64(double x) {                    // |x| <= 150
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const int k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double hi = x - (double)k * ln2HI, lo = (double)k * ln2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    uint64_t u;                                        // y in [0.7, 1.5), |k| <= 217: scale by adding k to the exponent field
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = (uint64_t)__double_as_longlong(y);
+#else
+    memcpy(&u, &y, 8);
+#endif
+    u += (uint64_t)((int64_t)k << 52);
+    double out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    out = __longlong_as_double((long long)u);
+#else
+    memcpy(&out, &u, 8);
+#endif
+    return out;
+}
+
+FT_HD float ft_pow(float x, float g) {
+    if (g == 0.0f) return 1.0f;
+    if (x != x || g != g) return NAN;
+    if (g == 1.0f) return x;
+    if (x < 0.0f) return NAN;                          // (MathF.Pow of a negative base and a non-integer exponent)
+    if (x == 0.0f) return g > 0.0f ? 0.0f : INFINITY;
+    if (x == INFINITY) return g > 0.0f ? INFINITY : 0.0f;
+    if (x == 1.0f) return 1.0f;
+    if (g == INFINITY || g == -INFINITY) return ((x < 1.0f) == (g > 0.0f)) ? 0.0f : INFINITY;
+    double y = (double)g * ft_log_f64((double)x);
+    y = y < -150.0 ? -150.0 : (y > 150.0 ? 150.0 : y);
+    return (float)ft_exp_f64(y);
+}
+
+// counter-based dither for the tone map: lowbias32 of (pixel, channel, seed) -> [0, 1) with 24 bits.  The reference
+// draws rng.range_01() from ONE System.Random shared by a parallel map (Image.fs:46-49): racy, not reproducible.
+FT_HD float ft_dither_u(uint32_t x, uint32_t y, uint32_t channel, uint32_t seed) {
+    uint32_t h = seed ^ (x * 0x9E3779B1u) ^ (y * 0x85EBCA77u) ^ (channel * 0xC2B2AE3Du);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// FColor.toColor (FColor.fs:43-48): c * 254.5f + u |> MathF.Round (half to even) |> int |> min 255.  A NaN or negative value,
+// where the reference's Color.FromArgb would throw, gives 0.
+FT_HD uint32_t ft_to_byte(float c, float u) {
+    const float v = c * 254.5f + u;
+    if (!(v >= 0.0f)) return 0u;
+    const float r = rintf(v);
+    return r >= 255.0f ? 255u : (uint32_t)r;
+}

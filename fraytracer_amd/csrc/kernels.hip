@@ -52,6 +52,22 @@ __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
     r.color[0] = q->color[0]; r.color[1] = q->color[1]; r.color[2] = q->color[2]; r.pad = 0.0f; return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dynamic LDS of a workgroup: [ FT_C_COUNT x FT_BLOCK per-lane statistics words | nSlots x FT_BLOCK value
+// slots (distance) | nSlots x FT_BLOCK slots (material) | staged prefix of the constant pool ].
+// Per-lane statistics live in LDS (word k * FT_BLOCK + tid), not in registers: seven counters would otherwise
+// stay live across the whole SDF evaluation.  One ds_add per event.  They sit first so that their address
+// does not depend on the scene: primitives can raise a flag without being handed a pointer.
+// ------------------------------------------------------------------------------------------------
+extern __shared__ float ft_lds[];
+enum : uint32_t { FT_C_EVALS = 0, FT_C_SHADOW, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
+__device__ __forceinline__ void ft_count(uint32_t k) {
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + k * FT_BLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ft_flag(uint32_t bits) {
+    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + FT_C_FLAGS * FT_BLOCK, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- square roots -----------------------------------------------------------------------------------------
 // ft_sqrt_fast: bit-identical to sqrtf for every float in [2^-96, 2^100] (proved by exhaustion,
 // ft_selftest_fastmath).  ft_sq<FQ>: FQ = false is the IEEE sqrtf.  FQ = true is used only where the
@@ -98,7 +114,9 @@ template <bool FQ> __device__ __forceinline__ float prim_torus(cfp c, f3 p) {
 template <bool FQ> __device__ __forceinline__ float prim_triangle(cfp c, f3 p) {
     const f3 p1 = p - ld3(c), p2 = p - ld3(c + 4), p3 = p - ld3(c + 8);   // :228-230
     float distance;
-    const int s = ft_sign_i(ft_dot(ld3(c + 40), p1)) + ft_sign_i(ft_dot(ld3(c + 44), p2)) + ft_sign_i(ft_dot(ld3(c + 48), p3));
+    const float e1 = ft_dot(ld3(c + 40), p1), e2 = ft_dot(ld3(c + 44), p2), e3 = ft_dot(ld3(c + 48), p3);
+    if (e1 != e1 || e2 != e2 || e3 != e3) ft_flag(2u);                 // MathF.Sign(NaN) throws in .NET (Math.fs:40): flag bit 1, sign taken as 0
+    const int s = ft_sign_i(e1) + ft_sign_i(e2) + ft_sign_i(e3);
     if (s < 2) {                                                       // :235-237
         const f3 v21 = ld3(c + 12), v32 = ld3(c + 16), v13 = ld3(c + 20);
         const float d21 = ft_distance2(p1, v21 * ft_clamp01(ft_dot(ld3(c + 24), p1)));   // :240
@@ -427,10 +445,8 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
             cfp c = consts + in.data;
             cfp bd = consts + in.aux;
             const uint32_t stride = prim_stride(in.type);
-            for (uint32_t i = 0; i < in.count; ++i) {
-                const float v = prim_eval(in.type, c + i * stride, p);
-                if (mx < ft_distance(ld3(bd + 4 * i), p) + bd[4 * i + 3]) mx = ft_max(mx, v);
-            }
+            for (uint32_t i = 0; i < in.count; ++i)                  // the child is evaluated only where the reference calls it (:62-63)
+                if (mx < ft_distance(ld3(bd + 4 * i), p) + bd[4 * i + 3]) mx = ft_max(mx, prim_eval(in.type, c + i * stride, p));
             *dst = mx;
             break;
         }
@@ -518,18 +534,6 @@ __constant__ float FT_AO_DIRS[16][3] = {
     {0x1.046c0ap-3f, 0x1.a248a2p-1f, -0x1.200000p-1f}, {0x1.9bff54p-2f, -0x1.3585eap-1f, -0x1.600000p-1f},
     {-0x1.21c850p-1f, 0x1.1e0d66p-3f, -0x1.a00000p-1f}, {0x1.38c4f8p-2f, 0x1.55799ap-3f, -0x1.e00000p-1f}};
 
-extern __shared__ float ft_lds[];
-
-// Per-lane statistics live in LDS (word k * FT_BLOCK + tid behind the staged constants), not in registers:
-// seven counters would otherwise stay live across the whole SDF evaluation.  One ds_add per event.
-enum : uint32_t { FT_C_EVALS = 0, FT_C_SHADOW, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
-__device__ __forceinline__ void ft_count(uint32_t cnt, uint32_t k) {
-    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + cnt + k * FT_BLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void ft_flag(uint32_t cnt, uint32_t bits) {
-    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(ft_lds) + cnt + FT_C_FLAGS * FT_BLOCK, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 struct LaneState {
     uint32_t phase, job, steps, lidx, leaf, outIdx;
     f3 o, dir;            // current ray (primary, then the shadow ray of light lidx)
@@ -543,7 +547,6 @@ struct LaneState {
     float sign;               // EXTENSION glass: +1 outside, -1 inside (the march runs on sign * Distance)
     f3 thr;                   // EXTENSION: path throughput (wavelength weight x tints)
     uint32_t bounce, seed;    // EXTENSION glass: interactions so far, per-sample hash seed
-    uint32_t cnt;             // this lane's first statistics word in LDS (ft_count)
 };
 
 __device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx, f3 c) {
@@ -601,7 +604,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
                 continue;
             }
             const f3 dir = ft_normalize(s.nrm + mk3(FT_AO_DIRS[s.aoIdx][0], FT_AO_DIRS[s.aoIdx][1], FT_AO_DIRS[s.aoIdx][2]));
-            ft_count(s.cnt, FT_C_EXT);
+            ft_count(FT_C_EXT);
             if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.aoOpen += 1; s.aoIdx += 1; continue; }
             s.o = s.hp; s.dir = dir; s.len = a.aoRadius; s.steps = 0;
             s.phase = PH_AO;
@@ -642,7 +645,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
                     s.len = sqrtf(distance2);
                     s.lint = lc / distance2;                           // :40
                 }
-                s.steps = 0; ft_count(s.cnt, FT_C_SHADOW);
+                s.steps = 0; ft_count(FT_C_SHADOW);
                 s.phase = PH_SHADOW;
                 continue;
             }
@@ -685,7 +688,7 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
         }
     }
     if (EXT) { s.sign = 1.0f; s.bounce = 0; }
-    s.steps = 0; ft_count(s.cnt, FT_C_PRIMARY);
+    s.steps = 0; ft_count(FT_C_PRIMARY);
     s.phase = PH_MARCH;
     settle<EXT>(a, s);
 }
@@ -724,7 +727,7 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
         const float u = (float)(ft_glass_hash(s.seed, s.bounce) >> 8) * (1.0f / 16777216.0f);
         reflect = u < reflectance;
     }
-    ft_count(s.cnt, FT_C_EXT);
+    ft_count(FT_C_EXT);
     if (reflect) {
         s.dir = ft_normalize(D + N * (2.0f * cosi));                   // Light.fs:56
         s.o = s.hp + N * (2.0f * s.eps);
@@ -748,10 +751,11 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 template <int VARIANT, bool EXT>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    float* sd = ft_lds + tid;
-    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + a.S.nSlots * FT_BLOCK) + tid;
-    float* ldsC = ft_lds + 2u * a.S.nSlots * FT_BLOCK;                // staged constant pool ("SDF op stack" in LDS)
+    float* sd = ft_lds + FT_C_COUNT * FT_BLOCK + tid;
+    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + (FT_C_COUNT + a.S.nSlots) * FT_BLOCK) + tid;
+    float* ldsC = ft_lds + (FT_C_COUNT + 2u * a.S.nSlots) * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
     for (uint32_t i = tid; i < a.S.nStage; i += FT_BLOCK) ldsC[i] = a.S.consts[i];
+    for (uint32_t k = 0; k < FT_C_COUNT; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
     __syncthreads();
 
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
@@ -761,8 +765,6 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
     s.o = s.dir = s.hp = s.nrm = s.lacc = s.lint = mk3(0, 0, 0);
     s.len = 0; s.eps = 0; s.lcos = 0;
-    s.cnt = 2u * a.S.nSlots * FT_BLOCK + a.S.nStage + tid;
-    for (uint32_t k = 0; k < FT_C_COUNT; ++k) reinterpret_cast<uint32_t*>(ft_lds)[s.cnt + k * FT_BLOCK] = 0u;
     s.aoIdx = s.aoOpen = 0;
     s.sign = 1.0f; s.thr = splat3(1.0f); s.bounce = 0; s.seed = 0;
 
@@ -805,7 +807,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             float d; uint32_t leaf;
             if (VARIANT == 1 || VARIANT == 3) ft_eval_smooth_spheres<VARIANT == 3>(a.S, q, ldsC, d, leaf);
             else ft_eval<VARIANT == 2>(a.S, q, sd, sl, ldsC, d, leaf);
-            ft_count(s.cnt, FT_C_EVALS);
+            ft_count(FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
 
             switch (s.phase) {
@@ -813,10 +815,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             case PH_SHADOW:
             case PH_AO: {
                 bool miss = false;
-                if (d != d) { ft_flag(s.cnt, 1u); miss = true; }           // reference would never terminate
+                if (d != d) { ft_flag(1u); miss = true; }           // reference would never terminate
                 else if (d < s.eps) {                                  // SdfForm.fs:98
                     if (s.phase == PH_MARCH) {
-                        ft_count(s.cnt, FT_C_HITP); s.leaf = leaf; s.phase = PH_NX;
+                        ft_count(FT_C_HITP); s.leaf = leaf; s.phase = PH_NX;
                         if (EXT && a.mode == 2u) {                     // SdfForm.tryTrace: {Ray = ray; Distance = distance} (SdfForm.fs:98-102)
                             float* o = a.out + 10ull * s.outIdx;
                             write_ray(o, s.o, s.dir, s.len, s.eps);
@@ -824,13 +826,13 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                             s.phase = PH_IDLE;
                         }
                     }
-                    else if (s.phase == PH_SHADOW) { ft_count(s.cnt, FT_C_HITS); s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
+                    else if (s.phase == PH_SHADOW) { ft_count(FT_C_HITS); s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
                     else { s.aoIdx += 1; s.phase = PH_AONEXT; }        // EXTENSION: occluded
                 } else {
                     s.o = s.o + s.dir * d;                             // Ray.move (Ray.fs:9-13)
                     s.len = s.len - d;
                     s.steps += 1;
-                    if (s.steps >= FT_STEP_CAP) { ft_flag(s.cnt, 4u); miss = true; }
+                    if (s.steps >= FT_STEP_CAP) { ft_flag(4u); miss = true; }
                 }
                 if (miss) s.len = -1.0f;                               // resolved as a miss by settle()
                 break;
@@ -863,12 +865,12 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     }
 
     // ---- statistics -------------------------------------------------------------------------
-    const uint32_t* cw = reinterpret_cast<const uint32_t*>(ft_lds) + s.cnt;
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(ft_lds) + tid;
     const unsigned long long e = wave_sum(cw[FT_C_EVALS * FT_BLOCK]), sh = wave_sum(cw[FT_C_SHADOW * FT_BLOCK]),
                              hp = wave_sum(cw[FT_C_HITP * FT_BLOCK]), hs = wave_sum(cw[FT_C_HITS * FT_BLOCK]),
                              pr = wave_sum(cw[FT_C_PRIMARY * FT_BLOCK]), ex = wave_sum(cw[FT_C_EXT * FT_BLOCK]);
     const uint32_t cFlags = cw[FT_C_FLAGS * FT_BLOCK];
-    const unsigned long long fl = __ballot((cFlags & 1u) != 0) ? 1ull : 0ull;
+    const unsigned long long fl = (__ballot((cFlags & 1u) != 0) ? 1ull : 0ull) | (__ballot((cFlags & 2u) != 0) ? 2ull : 0ull);
     const unsigned long long fc = __ballot((cFlags & 4u) != 0) ? 4ull : 0ull;
     if (lane == 0) {
         atomicAdd(&a.stats->sdf_evals, e);
@@ -900,9 +902,9 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
                                                                             long long n, float* __restrict__ outD, int* __restrict__ outM) {
     const uint32_t tid = threadIdx.x;
-    float* sd = ft_lds + tid;
-    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + S.nSlots * FT_BLOCK) + tid;
-    float* ldsC = ft_lds + 2u * S.nSlots * FT_BLOCK;
+    float* sd = ft_lds + FT_C_COUNT * FT_BLOCK + tid;              // same LDS layout as the trace kernel (flag words first, unused here)
+    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + (FT_C_COUNT + S.nSlots) * FT_BLOCK) + tid;
+    float* ldsC = ft_lds + (FT_C_COUNT + 2u * S.nSlots) * FT_BLOCK;
     for (uint32_t i = tid; i < S.nStage; i += FT_BLOCK) ldsC[i] = S.consts[i];
     __syncthreads();
     for (long long i = (long long)blockIdx.x * FT_BLOCK + tid; i < n; i += (long long)gridDim.x * FT_BLOCK) {
@@ -936,6 +938,80 @@ extern "C" __global__ void ft_resolve_kernel(const float* __restrict__ planes, f
         float c = planes[i];
         for (unsigned k = 1; k < spp; ++k) c = c + planes[(unsigned long long)k * nFloats + i];
         out[i] = c / (float)spp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tone map on the device: Image.toColors (Image.fs:37-50) + FColor.gammaInverse / toColor
+// (FColor.fs:43-55) + the scan-line order of Image.toBitmap (Image.fs:61-86).  HBM-bound: 12 B/pixel read twice
+// (max pass, map pass; the second read mostly hits the L2 / MALL for frames up to a few hundred MB), 3 B/pixel
+// written; the frame leaves the GPU as 3 bytes per pixel instead of 12.
+// ------------------------------------------------------------------------------------------------
+// pass 1: max over all channels of max(0.01, c) (Image.fs:40-43; every candidate is >= 0.01 > 0, so unsigned
+// integer comparison of the bit patterns orders them; NaN channels are ignored like v_max_f32 does)
+extern "C" __global__ void __launch_bounds__(256) ft_tonemap_max_kernel(const float* __restrict__ frame, unsigned long long nFloats, uint32_t* __restrict__ maxBits) {
+    float m = 0.01f;
+    const unsigned long long n4 = nFloats / 4ull;
+    const float4* f4 = reinterpret_cast<const float4*>(frame);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float4 v = f4[i];
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(v.x, v.y), __builtin_fmaxf(v.z, v.w)));
+    }
+    for (unsigned long long i = n4 * 4ull + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nFloats; i += (unsigned long long)gridDim.x * blockDim.x)
+        m = __builtin_fmaxf(m, frame[i]);
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_down(m, off, 64));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = __builtin_fmaxf(__builtin_fmaxf(part[0], part[1]), __builtin_fmaxf(part[2], part[3]));
+        atomicMax(maxBits, __float_as_uint(m));
+    }
+}
+
+__device__ __forceinline__ uint32_t tonemap_pixel(const float* __restrict__ px, float mx, float gammaInv, uint32_t dither, uint32_t seed, uint32_t x, uint32_t y) {
+    // fcolor / max |> gammaInverse gammaInv |> toColor rng  (Image.fs:47-49): R, G, B in the order the reference draws its noise
+    const float r = ft_pow(px[0] / mx, gammaInv), g = ft_pow(px[1] / mx, gammaInv), b = ft_pow(px[2] / mx, gammaInv);
+    const float ur = dither ? ft_dither_u(x, y, 0u, seed) : 0.5f, ug = dither ? ft_dither_u(x, y, 1u, seed) : 0.5f, ub = dither ? ft_dither_u(x, y, 2u, seed) : 0.5f;
+    return ft_to_byte(r, ur) | (ft_to_byte(g, ug) << 8) | (ft_to_byte(b, ub) << 16);
+}
+
+// pass 2, Color[X,Y] order: out[(x * Y + y) * 3 + {0,1,2}] = R, G, B  (the value of Image.toColors)
+extern "C" __global__ void __launch_bounds__(256) ft_tonemap_map_kernel(const float* __restrict__ frame, uint32_t X, uint32_t Y, const uint32_t* __restrict__ maxBits,
+                                                                       float gammaInv, uint32_t dither, uint32_t seed, unsigned char* __restrict__ out) {
+    const float mx = __uint_as_float(*maxBits);
+    const unsigned long long n = (unsigned long long)X * Y;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(i / Y), y = (uint32_t)(i - (unsigned long long)x * Y);
+        const uint32_t c = tonemap_pixel(frame + 3ull * i, mx, gammaInv, dither, seed, x, y);
+        unsigned char* o = out + 3ull * i;
+        o[0] = (unsigned char)c; o[1] = (unsigned char)(c >> 8); o[2] = (unsigned char)(c >> 16);
+    }
+}
+
+// pass 2, bitmap order (Image.toBitmap, Image.fs:61-86: after the index arithmetic and Array.rev the scan0 buffer holds, at
+// row r from the top and column c, the pixel image[X-1-c, r] as bytes B, G, R; stride X * 3).  A 64 x 64 tile is read with
+// y fastest (contiguous in the frame), turned in LDS and written with c fastest (contiguous in the bitmap).
+#define FT_TM_TILE 64
+extern "C" __global__ void __launch_bounds__(256) ft_tonemap_bmp_kernel(const float* __restrict__ frame, uint32_t X, uint32_t Y, const uint32_t* __restrict__ maxBits,
+                                                                       float gammaInv, uint32_t dither, uint32_t seed, unsigned char* __restrict__ out) {
+    __shared__ uint32_t tile[FT_TM_TILE][FT_TM_TILE + 1];
+    const float mx = __uint_as_float(*maxBits);
+    const uint32_t tilesY = (Y + FT_TM_TILE - 1) / FT_TM_TILE;
+    const uint32_t x0 = (blockIdx.x / tilesY) * FT_TM_TILE, y0 = (blockIdx.x % tilesY) * FT_TM_TILE;
+    for (uint32_t k = threadIdx.x; k < FT_TM_TILE * FT_TM_TILE; k += 256) {
+        const uint32_t lx = k / FT_TM_TILE, ly = k % FT_TM_TILE, x = x0 + lx, y = y0 + ly;
+        if (x < X && y < Y) tile[lx][ly] = tonemap_pixel(frame + 3ull * ((unsigned long long)x * Y + y), mx, gammaInv, dither, seed, x, y);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < FT_TM_TILE * FT_TM_TILE; k += 256) {
+        const uint32_t ly = k / FT_TM_TILE, lc = k % FT_TM_TILE;             // consecutive threads: consecutive bitmap columns
+        const uint32_t lx = FT_TM_TILE - 1 - lc, x = x0 + lx, y = y0 + ly;
+        if (x < X && y < Y) {
+            const uint32_t c = tile[lx][ly];
+            unsigned char* o = out + 3ull * ((unsigned long long)y * X + (X - 1u - x));
+            o[0] = (unsigned char)(c >> 16); o[1] = (unsigned char)(c >> 8); o[2] = (unsigned char)c;     // B, G, R
+        }
     }
 }
 
@@ -1059,6 +1135,24 @@ extern "C" hipError_t ft_launch_grid_compact(const FtItem* tmp, const uint32_t* 
 }
 extern "C" hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st) {
     hipLaunchKernelGGL(ft_resolve_kernel, dim3(2048), dim3(256), 0, st, planes, out, nFloats, spp);
+    return hipGetLastError();
+}
+extern "C" hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_t* maxBits, float gammaInv, uint32_t dither, uint32_t seed,
+                                        int bmpOrder, unsigned char* out, unsigned numCUs, hipStream_t st) {
+    const unsigned long long nFloats = 3ull * X * Y;
+    hipError_t e = hipMemsetAsync(maxBits, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    const unsigned maxBlocks = numCUs * 8u;
+    const unsigned long long want = (nFloats / 4ull + 255ull) / 256ull;
+    hipLaunchKernelGGL(ft_tonemap_max_kernel, dim3((unsigned)(want < 1 ? 1 : (want < maxBlocks ? want : maxBlocks))), dim3(256), 0, st, frame, nFloats, maxBits);
+    if (bmpOrder) {
+        const unsigned tiles = ((X + FT_TM_TILE - 1) / FT_TM_TILE) * ((Y + FT_TM_TILE - 1) / FT_TM_TILE);
+        hipLaunchKernelGGL(ft_tonemap_bmp_kernel, dim3(tiles), dim3(256), 0, st, frame, X, Y, (const uint32_t*)maxBits, gammaInv, dither, seed, out);
+    } else {
+        const unsigned long long wantP = ((unsigned long long)X * Y + 255ull) / 256ull;
+        hipLaunchKernelGGL(ft_tonemap_map_kernel, dim3((unsigned)(wantP < maxBlocks * 4ull ? wantP : maxBlocks * 4ull)), dim3(256), 0, st, frame, X, Y,
+                           (const uint32_t*)maxBits, gammaInv, dither, seed, out);
+    }
     return hipGetLastError();
 }
 extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st) {

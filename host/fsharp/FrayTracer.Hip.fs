@@ -28,6 +28,16 @@ type FtStats =
     { RaysPrimary : uint64; RaysShadow : uint64; RaysExt : uint64; HitsPrimary : uint64; HitsShadow : uint64
       SdfEvals : uint64; Flags : uint64; KernelMs : float32; Reserved : float32; WaveEvals : uint64 }
 
+/// ft_camera (48 B).  The reference's `Camera` (Camera.fs:16-22) is an ordinary F# record — a reference type with
+/// automatic layout, NOT a [<Struct>] — so it cannot cross P/Invoke by reference; its four vectors are copied into
+/// this blittable twin for the call (`FtCamera.ofCamera`).  `Lens` and `Camera.LookAt` are reference records too and
+/// never cross the boundary (Camera.lookAt stays on the F# side).
+[<Struct; StructLayout(LayoutKind.Sequential)>]
+type FtCamera =
+    { Position : Vector3; Forward : Vector3; UpScaled : Vector3; RightScaled : Vector3 }
+    static member ofCamera (c : Camera) : FtCamera =
+        { Position = c.Position; Forward = c.Forward; UpScaled = c.UpScaled; RightScaled = c.RightScaled }
+
 /// ft_form_trace_result: SdfFormTraceResult voption (Types.fs:32-37), Hit = 0 is ValueNone
 [<Struct; StructLayout(LayoutKind.Sequential)>]
 type FtFormTraceResult = { Ray : Ray; Distance : float32; Hit : int }
@@ -43,7 +53,10 @@ module Native =
     [<DllImport(Lib)>] extern int ft_ctx_create(int device, nativeint& ctx)
     [<DllImport(Lib)>] extern void ft_ctx_destroy(nativeint ctx)
     [<DllImport(Lib)>] extern nativeint ft_last_error()
-    // the reference's [<Struct>] primitive records are sequential float-only layouts (SdfForm.fs:118-212)
+    // By-reference parameters are [<Struct>] types only.  The reference's primitive records (SdfForm.fs:118-212), Ray and
+    // SdfBoundary (Types.fs:9-24) are [<Struct>] records of float32 / Vector3 fields: sequential, blittable.  Vector3 is a
+    // blittable BCL struct.  Camera, Lens, Camera.LookAt, SdfForm, SdfMaterial, SdfObject, SdfScene are reference records
+    // and are never passed: Camera goes through FtCamera, the others through integer handles.
     [<DllImport(Lib)>] extern int ft_form_sphere(nativeint ctx, SdfForm.Primitive.Sphere& data)
     [<DllImport(Lib)>] extern int ft_form_capsule(nativeint ctx, SdfForm.Primitive.Capsule& data)
     [<DllImport(Lib)>] extern int ft_form_torus(nativeint ctx, SdfForm.Primitive.Torus& data)
@@ -64,7 +77,7 @@ module Native =
     [<DllImport(Lib)>] extern void ft_scene_destroy(nativeint scene)
     [<DllImport(Lib)>] extern int ft_form_try_trace(nativeint ctx, nativeint scene, Ray[] rays, int64 n, [<Out>] FtFormTraceResult[] out, FtStats& stats)
     [<DllImport(Lib)>] extern int ft_object_try_trace(nativeint ctx, nativeint scene, Ray[] rays, int64 n, [<Out>] FtObjectTraceResult[] out, FtStats& stats)
-    [<DllImport(Lib)>] extern int ft_render(nativeint ctx, nativeint scene, Camera& camera, FtRenderParams& p, nativeint out, FtStats& stats)
+    [<DllImport(Lib)>] extern int ft_render(nativeint ctx, nativeint scene, FtCamera& camera, FtRenderParams& p, nativeint out, FtStats& stats)
 
     /// one context for the process (GPU 0); there is no CPU fallback inside the library
     let ctx =
@@ -220,7 +233,7 @@ module Image =
             let image : FColor[,] = Array2D.zeroCreate imageSize.X imageSize.Y
             let pin = GCHandle.Alloc (image, GCHandleType.Pinned)                                // as Image.fs:77-86 pins its buffer
             try
-                let mutable cam = camera
+                let mutable cam = FtCamera.ofCamera camera                                         // Camera is a reference record: copy into the blittable twin
                 let mutable p =
                     { Width = imageSize.X; Height = imageSize.Y; X0 = 0; NColumns = imageSize.X
                       StripeWidth = imageSize.X; StripeRanks = 1; StripeRank = 0; Spp = 1

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 2
+#define FT_ABI_VERSION 3
 
 typedef enum ft_status {
     FT_OK = 0,
@@ -150,6 +150,33 @@ int ft_render_device(ft_ctx*, const ft_scene*, const ft_camera*, const ft_render
                      void* d_out);
 /* counters / kernel time of the launches since the last call; synchronises the stream */
 int ft_collect_stats(ft_ctx*, ft_stats* stats);
+
+/* ---- around the hot path: tone map + 8-bit output -------------------------------- */
+/* Image.toColors gamma rng image (Image.fs:37-50): max = Max(0.01, max over all channels); per channel
+ * Pow(c / max, 1 / gamma) * 254.5 + u, rounded half-to-even, `min 255` (FColor.fs:43-55).  The reference draws u from one
+ * System.Random shared by a parallel map (racy, not reproducible): here u is 0.5 (dither = 0) or a counter-based hash of
+ * (x, y, channel, seed) in [0, 1) (dither = 1) — comparable to the reference to +-1 LSB.  MathF.Pow is platform libm;
+ * the library uses one fixed double-precision algorithm (ft_math.h ft_pow) shared with the test oracle.
+ * bmp_order = 0: out[(x * Y + y) * 3 + k] = R, G, B of image[x, y] — the Color[X,Y] value of Image.toColors.
+ * bmp_order = 1: the scan0 buffer Image.toBitmap builds (Image.fs:61-86): row r from the top, column c holds
+ *                image[X-1-c, r] as bytes B, G, R, stride X * 3 — ready for a 24-bpp bitmap. */
+typedef struct ft_tonemap_params {
+    float gamma;                  /* Image.toColors' gamma (Program.fs:98 passes 2.2f) */
+    int32_t dither;               /* 0: u = 0.5 everywhere; 1: hashed noise */
+    uint32_t seed;
+    int32_t bmp_order;
+} ft_tonemap_params;
+/* frame in device memory (X x Y x 3 float32 as ft_render_device writes it) -> 8-bit image in device memory; asynchronous
+ * on the context's stream */
+int ft_tone_map_device(ft_ctx*, const void* d_frame, int32_t X, int32_t Y, const ft_tonemap_params*, void* d_out);
+/* same, 8-bit image copied to host memory (3 bytes per pixel cross PCIe instead of 12); *max_out = the normalisation */
+int ft_tone_map(ft_ctx*, const void* d_frame, int32_t X, int32_t Y, const ft_tonemap_params*, uint8_t* out, float* max_out);
+/* Image.toColors on a host FColor[X,Y] (drop-in for the reference call on an image that is already on the host) */
+int ft_tone_map_host(ft_ctx*, const float* frame, int32_t X, int32_t Y, const ft_tonemap_params*, uint8_t* out, float* max_out);
+/* Program.fs:90-100 in one call: Image.render + Image.toColors (+ toBitmap order) on the device; only the 8-bit image
+ * leaves the GPU.  The render parameters must describe the whole frame. */
+int ft_render_colors(ft_ctx*, const ft_scene*, const ft_camera*, const ft_render_params*, const ft_tonemap_params*,
+                     uint8_t* out, float* max_out, ft_stats* stats);
 
 /* SdfScene.trace over an explicit ray buffer (the "ray buffer" form): out_rgb is n x 3 floats. */
 int ft_trace_rays(ft_ctx*, const ft_scene*, const ft_ray* rays, int64_t n, float* out_rgb, ft_stats* stats);

@@ -66,6 +66,8 @@ def _load():
         "orc_material_glass": (C.c_int, [f3, C.c_float, C.c_float]),
         "orc_spectral_table": (C.c_int, [C.c_int, C.c_void_p]), "orc_glass_hash": (C.c_uint32, [C.c_uint32, C.c_uint32]),
         "orc_fresnel": (None, [C.c_float, C.c_float, f3, f3, C.c_void_p]),
+        "orc_powf": (C.c_float, [C.c_float, C.c_float]),
+        "orc_tone_map": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
         "orc_pixel_ray": (None, [f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f3]),
     }
     for name, (res, args) in sig.items():
@@ -247,3 +249,17 @@ def logf(x):
 def sqrtf(x):
     x = np.ascontiguousarray(x, np.float32); y = np.empty_like(x)
     lib.orc_sqrtf_array(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size); return y
+
+
+def tone_map(image, gamma=2.2, seed=None, bmp_order=False):
+    """Image.toColors gamma rng image (+ Image.toBitmap's buffer order): (uint8 [X, Y, 3] R,G,B or [Y, X, 3] B,G,R, max)"""
+    img = np.ascontiguousarray(image, np.float32)
+    X, Y = img.shape[0], img.shape[1]
+    out = np.empty((Y, X, 3) if bmp_order else (X, Y, 3), np.uint8)
+    mx = lib.orc_tone_map(img.ctypes.data_as(C.c_void_p), X, Y, gamma, 0 if seed is None else 1, 0 if seed is None else seed & 0xFFFFFFFF,
+                          1 if bmp_order else 0, out.ctypes.data_as(C.c_void_p))
+    return out, float(mx)
+
+
+def powf(x, g):
+    return lib.orc_powf(x, g)

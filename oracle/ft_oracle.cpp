@@ -1214,3 +1214,91 @@ void orc_pixel_ray(const float cam[12], int W, int H, int x, int y, float epsilo
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Post-processing: Image.toColors (Image.fs:37-50), FColor.gammaInverse / toColor (FColor.fs:43-55),
+// Image.toBitmap's buffer order (Image.fs:61-86).  MathF.Pow is platform libm in .NET; like exp / log it is replaced
+// by one fixed algorithm (exp(g * log x) in double from + - * / only, rounded to float once) that the product carries
+// its own copy of.  The reference draws the noise from one System.Random shared by a parallel map (racy); the noise
+// here is 0.5 or a counter-based hash of (x, y, channel, seed) — the reference is comparable to +-1 LSB only.
+// ---------------------------------------------------------------------------
+static double orc_exp_double(double x) {                             // fdlibm e_exp.c structure, |x| <= 150
+    static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const int k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double hi = x - (double)k * ln2HI, lo = (double)k * ln2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    uint64_t u; memcpy(&u, &y, 8);
+    u += (uint64_t)((int64_t)k << 52);
+    double out; memcpy(&out, &u, 8);
+    return out;
+}
+static float orc_powf_impl(float x, float g) {                       // MathF.Pow(x, g), FColor.fs:52-54
+    if (g == 0.0f) return 1.0f;
+    if (x != x || g != g) return NAN;
+    if (g == 1.0f) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return g > 0.0f ? 0.0f : INFINITY;
+    if (x == INFINITY) return g > 0.0f ? INFINITY : 0.0f;
+    if (x == 1.0f) return 1.0f;
+    if (g == INFINITY || g == -INFINITY) return ((x < 1.0f) == (g > 0.0f)) ? 0.0f : INFINITY;
+    double y = (double)g * orc_log_double((double)x);
+    y = y < -150.0 ? -150.0 : (y > 150.0 ? 150.0 : y);
+    return (float)orc_exp_double(y);
+}
+static float orc_dither(uint32_t x, uint32_t y, uint32_t channel, uint32_t seed) {
+    uint32_t h = seed ^ (x * 0x9E3779B1u) ^ (y * 0x85EBCA77u) ^ (channel * 0xC2B2AE3Du);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// FColor.toColor, one channel (FColor.fs:45): c * 254.5f + rng.range_01() |> MathF.round_i |> min 255.  MathF.Round is
+// round-half-to-even (Math.fs:54,58).  Where Color.FromArgb would throw (NaN -> conv.i4 = INT_MIN, or a negative value)
+// the byte is 0.
+static uint8_t orc_to_byte(float c, float u) {
+    const float v = c * 254.5f + u;
+    if (!(v >= 0.0f)) return 0;
+    const float r = rintf(v);                                        // default rounding mode: half to even
+    return r >= 255.0f ? 255 : (uint8_t)(int)r;
+}
+
+extern "C" {
+float orc_powf(float x, float g) { return orc_powf_impl(x, g); }
+
+// image: FColor[X,Y] as X x Y x 3 floats.  bmp_order = 0: out = Color[X,Y] as R,G,B bytes (Image.toColors' value);
+// 1: the buffer of Image.toBitmap after Array.rev (Image.fs:65-74): entry k = index' -> x = index' % X, y = Y-1 - index'/X
+// with index' = X*Y-1-k, stored B,G,R.  Returns the normalisation `max` (Image.fs:40-43).
+float orc_tone_map(const float* image, int X, int Y, float gamma, int dither, uint32_t seed, int bmp_order, uint8_t* out) {
+    const float gammaInv = 1.0f / gamma;                             // Image.fs:38
+    float mx = -INFINITY;                                            // Array2D.Parallel.maxWith FColor.getMaxColor (Image.fs:41-42)
+    for (int x = 0; x < X; ++x)
+        for (int y = 0; y < Y; ++y) {
+            const float* c = image + 3 * ((size_t)x * Y + y);
+            const float m = fs_max(c[2], fs_max(c[1], c[0]));        // Math.fs:83: v.X |> MathF.max v.Y |> MathF.max v.Z
+            if (m > mx) mx = m;
+        }
+    mx = fs_max(0.01f, mx);                                          // Image.fs:43
+    std::vector<uint8_t> colors((size_t)X * Y * 3);
+    for (int x = 0; x < X; ++x)
+        for (int y = 0; y < Y; ++y) {
+            const float* c = image + 3 * ((size_t)x * Y + y);
+            uint8_t* o = colors.data() + 3 * ((size_t)x * Y + y);
+            for (int k = 0; k < 3; ++k) {                            // fcolor / max |> gammaInverse gammaInv |> toColor rng (Image.fs:47-49); R, G, B
+                const float v = orc_powf_impl(c[k] / mx, gammaInv);
+                o[k] = orc_to_byte(v, dither ? orc_dither((uint32_t)x, (uint32_t)y, (uint32_t)k, seed) : 0.5f);
+            }
+        }
+    if (!bmp_order) { memcpy(out, colors.data(), colors.size()); return mx; }
+    const size_t n = (size_t)X * Y;
+    for (size_t k = 0; k < n; ++k) {                                 // Image.fs:65-74
+        const size_t index = n - 1 - k;                              // Array.rev
+        const int x = (int)(index % (size_t)X), y = Y - 1 - (int)(index / (size_t)X);
+        const uint8_t* c = colors.data() + 3 * ((size_t)x * Y + y);
+        out[3 * k] = c[2]; out[3 * k + 1] = c[1]; out[3 * k + 2] = c[0];   // {B; G; R}
+    }
+    return mx;
+}
+}  // extern "C"

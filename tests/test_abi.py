@@ -35,7 +35,7 @@ def test_blittable_layouts_match_the_reference_records():
     assert C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Boundary) == 16 and C.sizeof(_lib.CameraS) == 48
     assert C.sizeof(_lib.Sphere) == 16 and C.sizeof(_lib.Capsule) == 28 and C.sizeof(_lib.Torus) == 32 and C.sizeof(_lib.Triangle) == 40
     assert C.sizeof(_lib.RenderParams) == 56 and C.sizeof(_lib.Stats) == 72
-    assert _lib.lib.ft_abi_version() == 2
+    assert _lib.lib.ft_abi_version() == 3
 
 
 def test_the_library_is_built_in_tree_and_is_not_the_oracle():
@@ -48,3 +48,69 @@ def test_the_library_is_built_in_tree_and_is_not_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 assert "oracle" not in open(os.path.join(dirpath, f), errors="ignore").read().replace("the oracle", "").replace("test oracle", "").replace("CPU oracle", ""), f
+
+
+C99_PROBE = r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "fraytracer_hip.h"
+#define S(t) printf("sizeof " #t " %zu\n", sizeof(t))
+#define O(t, f) printf("offsetof " #t "." #f " %zu\n", offsetof(t, f))
+int main(void) {
+    S(ft_vec3); S(ft_ray); S(ft_boundary); S(ft_form_trace_result); S(ft_object_trace_result); S(ft_sphere); S(ft_capsule);
+    S(ft_torus); S(ft_triangle); S(ft_box); S(ft_camera); S(ft_render_params); S(ft_stats); S(ft_scene_info); S(ft_handle);
+    S(ft_tonemap_params);
+    O(ft_ray, direction); O(ft_ray, length); O(ft_ray, epsilon); O(ft_boundary, radius);
+    O(ft_form_trace_result, distance); O(ft_form_trace_result, hit);
+    O(ft_object_trace_result, normal); O(ft_object_trace_result, color); O(ft_object_trace_result, hit);
+    O(ft_capsule, to); O(ft_capsule, radius); O(ft_torus, normal); O(ft_torus, major_radius); O(ft_torus, minor_radius);
+    O(ft_triangle, v2); O(ft_triangle, v3); O(ft_triangle, radius); O(ft_box, half_extent);
+    O(ft_camera, forward); O(ft_camera, up_scaled); O(ft_camera, right_scaled);
+    O(ft_render_params, x0); O(ft_render_params, stripe_width); O(ft_render_params, spp); O(ft_render_params, epsilon);
+    O(ft_render_params, length); O(ft_render_params, ao_samples); O(ft_render_params, ao_radius); O(ft_render_params, max_bounces);
+    O(ft_render_params, spectral);
+    O(ft_stats, hits_primary); O(ft_stats, sdf_evals); O(ft_stats, flags); O(ft_stats, kernel_ms); O(ft_stats, reserved); O(ft_stats, wave_evals);
+    O(ft_tonemap_params, gamma); O(ft_tonemap_params, dither); O(ft_tonemap_params, seed); O(ft_tonemap_params, bmp_order);
+    return 0;
+}
+"""
+
+
+def test_header_is_plain_c99_with_the_reference_layouts(tmp_path):
+    """The boundary is usable from C (and so from any FFI): the header compiles as strict C99 on its own, and a C
+    program — not ctypes — reports the sizes / offsets the F# [<Struct>] records and the P/Invoke twins rely on
+    (Types.fs:9-24, 32-37, 57-65; SdfForm.fs:118-212; FtCamera / FtRenderParams / FtStats in host/fsharp)."""
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", HEADER])
+    src = tmp_path / "probe.c"
+    src.write_text(C99_PROBE)
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-o", str(exe), str(src)])
+    got = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        kind, name, val = line.split()
+        got[(kind, name)] = int(val)
+    want_sizes = {"ft_vec3": 12, "ft_ray": 32, "ft_boundary": 16, "ft_form_trace_result": 40, "ft_object_trace_result": 64,
+                  "ft_sphere": 16, "ft_capsule": 28, "ft_torus": 32, "ft_triangle": 40, "ft_box": 24, "ft_camera": 48,
+                  "ft_render_params": 56, "ft_stats": 72, "ft_scene_info": 40, "ft_handle": 4, "ft_tonemap_params": 16}
+    for k, v in want_sizes.items():
+        assert got[("sizeof", k)] == v, (k, got[("sizeof", k)], v)
+    want_offsets = {"ft_ray.direction": 12, "ft_ray.length": 24, "ft_ray.epsilon": 28, "ft_boundary.radius": 12,
+                    "ft_form_trace_result.distance": 32, "ft_form_trace_result.hit": 36,
+                    "ft_object_trace_result.normal": 32, "ft_object_trace_result.color": 44, "ft_object_trace_result.hit": 56,
+                    "ft_capsule.to": 12, "ft_capsule.radius": 24, "ft_torus.normal": 12, "ft_torus.major_radius": 24,
+                    "ft_torus.minor_radius": 28, "ft_triangle.v2": 12, "ft_triangle.v3": 24, "ft_triangle.radius": 36,
+                    "ft_box.half_extent": 12, "ft_camera.forward": 12, "ft_camera.up_scaled": 24, "ft_camera.right_scaled": 36,
+                    "ft_render_params.x0": 8, "ft_render_params.stripe_width": 16, "ft_render_params.spp": 28,
+                    "ft_render_params.epsilon": 32, "ft_render_params.length": 36, "ft_render_params.ao_samples": 40,
+                    "ft_render_params.ao_radius": 44, "ft_render_params.max_bounces": 48, "ft_render_params.spectral": 52,
+                    "ft_stats.hits_primary": 24, "ft_stats.sdf_evals": 40, "ft_stats.flags": 48, "ft_stats.kernel_ms": 56,
+                    "ft_stats.reserved": 60, "ft_stats.wave_evals": 64,
+                    "ft_tonemap_params.gamma": 0, "ft_tonemap_params.dither": 4, "ft_tonemap_params.seed": 8,
+                    "ft_tonemap_params.bmp_order": 12}
+    for k, v in want_offsets.items():
+        assert got[("offsetof", k)] == v, (k, got[("offsetof", k)], v)
+    # the ctypes mirror agrees with the C compiler
+    for cname, ctype in (("ft_ray", _lib.Ray), ("ft_camera", _lib.CameraS), ("ft_render_params", _lib.RenderParams), ("ft_stats", _lib.Stats),
+                         ("ft_triangle", _lib.Triangle), ("ft_torus", _lib.Torus), ("ft_capsule", _lib.Capsule)):
+        assert C.sizeof(ctype) == got[("sizeof", cname)], cname

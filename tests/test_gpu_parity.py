@@ -542,6 +542,23 @@ def test_nan_distances_are_flagged_identically(gpu, oracle):
     assert_bit_equal(g, o, "NaN scene")
     assert gst["flags"] & 1 and ocnt["flags"] & 1
     assert gst["hits_primary"] == ocnt["hits_primary"] == 0
+    # A ray with a NaN direction through triangles: after the first step the query point is NaN, the triangle's edge
+    # tests call MathF.Sign(NaN) (SdfForm.fs:235-237 — throws in .NET): flag bit 1 on both sides, then the NaN distance
+    # (bit 0).  Alone, inside a union (Items.[0] is evaluated unconditionally) and inside an intersect.
+    tri = lambda k: SdfForm.Primitive.triangle((-1 + k, -1, 0), (1 + k, -1, 0.2), (0 + k, 1, -0.1), 0.2)
+    mat = SdfMaterial.createSolid((0.3, 0.6, 0.9))
+    rays = np.array([[0, 0, -5, 0, 0, 1, 30, 0.01], [0, 0, -5, np.nan, 0, 1, 30, 0.01], [0.1, 0, -5, 0, np.nan, np.nan, 30, 0.01]], np.float32)
+    for obj, want_flags in ((SdfObject.create(mat, tri(0)), 3),
+                            (SdfObject.union([SdfObject.create(mat, tri(0)), SdfObject.create(mat, tri(0.5)), SdfObject.create(mat, tri(-0.5))]), 3),
+                            (SdfObject.create(mat, SdfForm.intersect([tri(0), tri(0.1), SdfForm.Primitive.sphere((0, 0, 0), 3.0)])), 3)):
+        sc = SdfScene(obj, syn.BACKGROUND, syn.program_lights())
+        ds, os_ = both(gpu, oracle, sc)
+        gg, gs = ds.trace_rays(rays)
+        oo, oc = os_.trace_rays(rays)
+        assert_bit_equal(gg, oo, "NaN-direction rays")
+        assert gs["flags"] == oc["flags"] == want_flags
+        g1, s1 = ds.trace_rays(rays[:1])                   # the healthy ray alone raises nothing
+        assert s1["flags"] == 0 and tuple(g1[0]) != tuple(np.float32(syn.BACKGROUND))
 
 
 def test_empty_and_degenerate_inputs(gpu, oracle):
@@ -592,6 +609,138 @@ def test_config3_full_frame_properties_and_sampled_oracle(gpu, oracle):
         ref = full.reshape(W // (R * S), R, S, H, 3)[:, r]
         assert_bit_equal(got, ref, f"stripe rank {r}")
     assert shadow == st["rays_shadow"]
+
+
+def test_config2_as_worded_boxes_and_ao_full_size(gpu, oracle):
+    """configs[1] as BASELINE.json words it: union of 16 spheres + 16 (EXTENSION) boxes, diffuse + 8 ambient-occlusion
+    rays per primary hit (EXTENSION), 1024x1024 — every pixel and every ray counter against the oracle."""
+    scene, size = syn.config2(boxes=True)
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    kw = dict(ao_samples=8, ao_radius=1.0)
+    g, gst = ds.render(EPS, LEN, size, cam, **kw)
+    o, ocnt = os_.render(EPS, LEN, size.X, size.Y, cam.as_array(), **kw)
+    assert size.X == size.Y == 1024
+    assert_bit_equal(g, o, "C2 (boxes + 8 AO rays) 1024^2")
+    check_counts(gst, ocnt)
+    assert gst["rays_ext"] == ocnt["rays_ext"] > 8 * 100000
+
+
+def test_config3_at_4_spp_full_size_sampled_oracle(gpu, oracle):
+    """configs[2] with its stated 4 samples per pixel (EXTENSION: 2x2 corner offsets, fixed-order resolve) at
+    4096x4096: every 64th column against the oracle's own 4-spp render, all counters of the frame exact."""
+    scene, size = syn.config3()
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    full, st = ds.render(EPS, LEN, size, cam, spp=4)
+    want, ocnt = os_.render(EPS, LEN, size.X, size.Y, cam.as_array(), xstep=64, spp=4)
+    assert size.X == size.Y == 4096
+    assert_bit_equal(full[::64], want, "C3 4096^2 at 4 spp, every 64th column")
+    assert st["rays_primary"] == 4 * size.X * size.Y and st["flags"] == 0
+    # sample 0 of the extension is the reference's sample: the 1-spp frame of the same columns bounds nothing, but the
+    # per-column ray counts of the sampled columns must agree with the oracle's
+    part, pst = ds.render(EPS, LEN, size, cam, spp=4, x0=2048, n_columns=1)
+    one, ocnt1 = os_.render(EPS, LEN, size.X, size.Y, cam.as_array(), x0=2048, x1=2049, spp=4)
+    assert_bit_equal(part, one, "column 2048 on its own")
+    for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow"):
+        assert pst[k] == ocnt1[k], k
+
+
+def test_config4_8192_sampled_oracle_and_stripes(gpu, oracle):
+    """configs[3]: the C3 scene at 8192x8192.  (a) every 128th column of the one-GPU frame against the oracle,
+    (b) the frame equals what 8 ranks' interleaved 16-column stripes concatenate to, (c) shadow-ray counts add up."""
+    scene, size = syn.config4()
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    W = H = size.X
+    assert W == 8192
+    full, st = ds.render(EPS, LEN, size, cam)
+    want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array(), xstep=128)
+    assert_bit_equal(full[::128], want, "C4 8192^2, every 128th column")
+    assert st["rays_primary"] == W * H and st["flags"] == 0
+    S, R = 16, 8
+    shadow = 0
+    ref = full.reshape(W // (R * S), R, S, H, 3)
+    for r in range(R):
+        slab, sst = ds.render(EPS, LEN, size, cam, stripe_width=S, stripe_ranks=R, stripe_rank=r, n_columns=W // R)
+        shadow += sst["rays_shadow"]
+        assert_bit_equal(slab.reshape(W // R // S, S, H, 3), ref[:, r], f"stripe rank {r}")
+        del slab
+    assert shadow == st["rays_shadow"]
+
+
+def test_program_fs_scene_full_size_against_oracle(gpu, oracle):
+    """The reference's only workload, src/FrayTracer.Console/Program.fs:14-83: System.Random(19), 1000 random tori,
+    subtract(intersect(union ..., sphere 3.5), sphere 2.5), directional + point light, 1000x1000 (Program.fs:24-26),
+    eps 0.01, length 30 — every pixel and every counter against the oracle."""
+    scene, size = syn.console_scene()
+    assert (size.X, size.Y) == (1000, 1000)
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
+    assert_bit_equal(g, o, "Program.fs scene 1000^2")
+    check_counts(gst, ocnt)
+    assert gst["hits_primary"] > 100000 and gst["rays_shadow"] > 100000
+    # and as the ray-buffer form of the same pixels (SdfScene.trace over Camera.uniformPixelToRay rays), one column
+    cam = syn.default_camera()
+    rays = np.stack([oracle.pixel_ray(cam.as_array(), 1000, 1000, 500, y, EPS, LEN) for y in range(1000)])
+    assert_bit_equal(gpu.scene(scene).trace_rays(rays)[0], o[500], "column 500 through ft_trace_rays")
+
+
+def test_config5_full_size_against_oracle(gpu, oracle):
+    """configs[4] (EXTENSION only): glass, 4 bounces, 16 wavelength bins, 2048x2048 at 16 spp — every 16th column
+    against the oracle's definition, counters of those columns exact."""
+    scene, size = syn.config5()
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    kw = dict(spp=16, spectral=16, max_bounces=4)
+    full, st = ds.render(EPS, LEN, size, cam, **kw)
+    want, ocnt = os_.render(EPS, LEN, size.X, size.Y, cam.as_array(), xstep=16, **kw)
+    assert_bit_equal(full[::16], want, "C5 2048^2 x 16 spp, every 16th column")
+    assert st["rays_primary"] == 16 * size.X * size.Y and st["flags"] == 0
+
+
+def test_tone_map_on_the_device_matches_the_oracle(gpu, oracle):
+    """Image.toColors (global max, Pow(c / max, 1 / gamma), x 254.5 + noise, half-to-even, min 255) and the
+    buffer order of Image.toBitmap as HIP kernels: byte-exact against the oracle's restatement, with and without noise,
+    in both orders; ragged sizes, black / NaN / huge pixels; the frame of the Program.fs scene end to end."""
+    rng = np.random.default_rng(21)
+    for (X, Y) in [(64, 64), (37, 101), (130, 19), (1, 1), (200, 65)]:
+        img = (rng.random((X, Y, 3)) ** 3 * 4.0).astype(np.float32)
+        if X > 30:
+            img[3, 2] = (np.nan, 0.0, -1.0); img[7, 1] = (np.inf, 1e30, 1e-30); img[9, 0] = 0.0
+        for gamma in (2.2, 1.0):
+            for seed in (None, 19):
+                for bmp in (False, True):
+                    want, wmx = oracle.tone_map(img, gamma=gamma, seed=seed, bmp_order=bmp)
+                    got = ft.Image.toColors(gamma, seed, img, gpu, bmp_order=bmp)
+                    assert got.shape == want.shape and np.array_equal(got, want), (X, Y, gamma, seed, bmp)
+    z = ft.Image.toColors(2.2, None, np.zeros((16, 8, 3), np.float32), gpu)
+    assert z.max() == 0
+    # end to end: Program.fs:90-100 — render + toColors on the device, 3 bytes per pixel come back
+    scene, size = syn.console_scene()
+    cam = syn.default_camera()
+    ds = gpu.scene(scene)
+    frame, st = ds.render(EPS, LEN, size, cam)
+    for seed, bmp in ((None, False), (19, True)):
+        got, mx, st2 = ds.render_colors(EPS, LEN, size, cam, gamma=2.2, seed=seed, bmp_order=bmp)
+        want, wmx = oracle.tone_map(frame, gamma=2.2, seed=seed, bmp_order=bmp)
+        assert mx == wmx == frame.max() and np.array_equal(got, want)
+        assert st2["rays_primary"] == st["rays_primary"] and st2["rays_shadow"] == st["rays_shadow"]
+    assert got.shape == (1000, 1000, 3) and got.max() == 255
+    with pytest.raises(ft.FrayTracerError):
+        ds.render_colors(EPS, LEN, size, cam, x0=8, n_columns=16)          # the normalisation needs the whole frame
+
+
+def test_tone_map_of_the_4096_frame_leaves_as_bytes(gpu, oracle):
+    """configs[2]'s 4096x4096 frame through ft_render_colors: 50 MB of bytes instead of 201 MB of floats cross PCIe, and
+    every byte equals the oracle's tone map of the float frame"""
+    scene, size = syn.config3()
+    cam = syn.default_camera()
+    ds = gpu.scene(scene)
+    frame, _ = ds.render(EPS, LEN, size, cam)
+    got, mx, _ = ds.render_colors(EPS, LEN, size, cam, gamma=2.2, seed=7, bmp_order=True)
+    want, wmx = oracle.tone_map(frame, gamma=2.2, seed=7, bmp_order=True)
+    assert got.nbytes == 4096 * 4096 * 3 and mx == wmx
+    assert np.array_equal(got, want)
 
 
 def test_device_grid_build_equals_host_build(gpu, oracle):
