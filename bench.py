@@ -151,7 +151,7 @@ def main():
         tot = None
         for d in lanes:
             st_ = d.collect_stats()
-            tot = st_ if tot is None else {k: (tot[k] if k == "lean_variant" else tot[k] + st_[k]) for k in tot}
+            tot = st_ if tot is None else {k: (min(tot[k], st_[k]) if k == "shader_mhz" else tot[k] + st_[k]) for k in tot}
         return tot
 
     def step():
@@ -265,7 +265,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "valu_busy_pmc": valu_busy,
-                         "kernel": "ft_trace_kernel_smooth_spheres" + ("_alt" if st.get("lean_variant") == 1 else ""),
+                         "kernel": "ft_trace_kernel_smooth_spheres",
                          "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "

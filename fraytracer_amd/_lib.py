@@ -67,12 +67,11 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_ext", C.c_uint64),
                 ("hits_primary", C.c_uint64), ("hits_shadow", C.c_uint64), ("sdf_evals", C.c_uint64),
-                ("flags", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_float), ("wave_evals", C.c_uint64)]
+                ("flags", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_float), ("wave_evals", C.c_uint64),
+                ("shader_mhz", C.c_float), ("reserved2", C.c_float)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
-        d["lean_variant"] = int(self.reserved)       # diagnostic: which placement of the lean kernel the context settled on
-        return d
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 class TonemapParams(C.Structure):

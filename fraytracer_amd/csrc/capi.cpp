@@ -39,8 +39,6 @@ struct ft_ctx {
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
     void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
     void* aux = nullptr; size_t auxBytes = 0;             // tone map: [256 B: max bits | 8-bit image]
-    int leanAlt[2] = {-1, -1};                             // lean kernel placement variant per (plain, EXTENSION) build; -1 = not timed yet
-    bool leanAltFinal[2] = {false, false};                 // timed on a frame of at least 2^20 jobs (a choice made on a smaller frame is provisional)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect (at most FT_MAX_PENDING_EVENTS)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
     double foldedMs = 0.0;                                 // kernel time of launches whose event pair was already recycled
@@ -206,46 +204,6 @@ int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
     return FT_OK;
 }
 
-// The lean smooth-sphere kernel is built with two placements of its inner loop (kernels.hip FT_LOOP_PHASE): which
-// one is the fast one differs between otherwise identical MI355X boxes (59 vs 63 ms per 4096^2 frame, either way
-// round).  Once per context, on the first frame with at least 2^18 jobs (512 x 512), both are timed on that frame's
-// first 2^20 jobs (alternating, twice each — four times each for frames below 2^20 jobs; the real launch then
-// overwrites those pixels with the same values) and the faster one is kept; a choice made on a frame below 2^20 jobs
-// is repeated on the first frame that has them.  FT_LEAN_ALT=0/1 forces the choice.
-int calibrateLean(ft_ctx* c, const ft_scene* s, const FtRenderArgs& a, unsigned blocks) {
-    const int e = a.ext ? 1 : 0;
-    if (const char* f = getenv("FT_LEAN_ALT")) { c->leanAlt[e] = atoi(f) != 0; c->leanAltFinal[e] = true; return FT_OK; }
-    FtStatsDev* tmpStats = nullptr;
-    HIP_TRY(hipMalloc((void**)&tmpStats, sizeof(FtStatsDev)));
-    HIP_TRY(hipMemsetAsync(tmpStats, 0, sizeof(FtStatsDev), c->stream));
-    hipEvent_t e0, e1;
-    int rc = acquireEvents(c, e0, e1);
-    if (rc) { (void)hipFree(tmpStats); return rc; }
-    float ms[2] = {0.0f, 0.0f};
-    hipError_t err = hipSuccess;
-    const int reps = a.nJobs >= (1u << 20) ? 4 : 8;
-    for (int rep = 0; rep < reps && err == hipSuccess; ++rep) {
-        FtRenderArgs b = a;
-        b.leanAlt = (uint32_t)(rep & 1);
-        b.nJobs = std::min<uint32_t>(a.nJobs, 1u << 20);
-        b.stats = tmpStats;
-        if ((err = hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream)) != hipSuccess) break;
-        if ((err = hipEventRecord(e0, c->stream)) != hipSuccess) break;
-        if ((err = ft_launch_trace(&b, blocks, ldsBytes(s), c->stream)) != hipSuccess) break;
-        if ((err = hipEventRecord(e1, c->stream)) != hipSuccess) break;
-        if ((err = hipEventSynchronize(e1)) != hipSuccess) break;
-        float t = 0.0f;
-        if ((err = hipEventElapsedTime(&t, e0, e1)) != hipSuccess) break;
-        ms[rep & 1] += t;
-    }
-    c->eventPool.emplace_back(e0, e1);
-    (void)hipFree(tmpStats);
-    if (err != hipSuccess) return hipFail(err, "lean kernel calibration");
-    c->leanAlt[e] = ms[1] < ms[0] ? 1 : 0;
-    c->leanAltFinal[e] = a.nJobs >= (1u << 20);
-    return FT_OK;
-}
-
 // launch the persistent trace kernel over nJobs jobs
 int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     int perCU = 0;
@@ -262,12 +220,6 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     a.stats = c->dStats;
     a.S = s->dev;
     a.materialsExt = s->dMaterialsExt;
-    if (s->dev.fastPath == 1) {
-        const int e = a.ext ? 1 : 0;
-        const bool wanted = (c->leanAlt[e] < 0 && a.nJobs >= (1u << 18)) || (!c->leanAltFinal[e] && a.nJobs >= (1u << 20));
-        if (wanted && a.mode == 0) { const int rc = calibrateLean(c, s, a, blocks); if (rc) return rc; }
-        a.leanAlt = c->leanAlt[e] > 0 ? 1u : 0u;
-    }
     HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
     hipEvent_t e0, e1;
     int rc = foldOldestEvents(c); if (rc) return rc;
@@ -529,7 +481,9 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
         st->rays_primary = h.rays_primary; st->rays_shadow = h.rays_shadow; st->rays_ext = h.rays_ext;
         st->hits_primary = h.hits_primary; st->hits_shadow = h.hits_shadow; st->sdf_evals = h.sdf_evals;
         st->flags = h.flags; st->kernel_ms = (float)ms; st->wave_evals = h.wave_evals;
-        st->reserved = (float)c->leanAlt[0];       // which placement of the lean kernel this context settled on (-1: not timed yet)
+        st->shader_mhz = h.clk_ref ? (float)((double)h.clk_shader / (double)h.clk_ref * 100.0) : 0.0f;   // s_memrealtime: 100 MHz
+        st->reserved2 = 0.0f;
+        st->reserved = 0.0f;
     }
     return FT_OK;
 }

@@ -103,6 +103,8 @@ struct FtSceneDev {             // passed by value as kernel argument
 
 struct FtStatsDev {
     unsigned long long rays_primary, rays_shadow, rays_ext, hits_primary, hits_shadow, sdf_evals, flags, wave_evals;
+    unsigned long long clk_shader, clk_ref;   // s_memtime / s_memrealtime ticks the first wave of block 0 lived (summed over launches):
+                                              // their ratio x the constant s_memrealtime rate (100 MHz) = the shader clock the kernel ran at
 };
 
 #define FT_STEP_CAP (1u << 20)  // the reference has no cap (SdfForm.fs:93-104); see DESIGN.md "NaN / step cap"

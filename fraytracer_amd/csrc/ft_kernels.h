@@ -26,7 +26,7 @@ struct FtRenderArgs {
     uint32_t ext;             // 1: launch the EXTENSION build of the kernel (set by the host, see capi.cpp)
     uint32_t maxBounces;      // EXTENSION glass: interactions per path; 0 = glass shades as a solid
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
-    uint32_t leanAlt;         // lean smooth-sphere kernel: 1 = the build with the other loop-placement parity (kernels.hip FT_LOOP_PHASE)
+    uint32_t pad2;
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move
     float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)

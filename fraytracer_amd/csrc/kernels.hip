@@ -206,32 +206,20 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 #ifndef FT_UNROLL
 #define FT_UNROLL 4
 #endif
-// Code placement of the hot loop: its speed depends on the 4-byte phase of the loop body inside the 64-byte
-// instruction-fetch lines (measured: 68.6 vs 74.5 ms per C3 frame between phases).  FT_LOOP_PHASE pins the
-// placement (64-byte boundary + FT_LOOP_PAD s_nops) so that unrelated edits cannot flip the mode.
-// Which parity of the pad is the fast one differs from box to box (same image, same binary: odd pads 59 ms /
-// even 63 ms on some MI355X, the reverse on others), so the lean kernel exists with both (ALT: pad - 1) and the
-// host times them once per context on the first large frame (capi.cpp calibrateLean).
-#ifndef FT_LOOP_PAD_NEAR
-#define FT_LOOP_PAD_NEAR 15
-#endif
-#ifndef FT_LOOP_PAD_FAR
-#define FT_LOOP_PAD_FAR 2
-#endif
+// Code placement of the hot loop.  The loop is ~72 four-byte instructions followed by one run of ~38 64-bit encoded VALU
+// instructions (the exp part); on gfx950 a frame takes 7 % more shader cycles when that run starts on an 8-byte boundary
+// than when it starts at 4 mod 8 (measured: profiles/r02_pad_sweep_*.jsonl, r02_asm_*.jsonl).  Which
+// one a plain compile produces depends on the dword count of the code in front.  FT_LOOP_PHASE marks the spot: the build's
+// layout pass (csrc/loop_layout.py, run by the Makefile on the device assembly) sets the number of s_nops behind the
+// 64-byte boundary to 0 or 1 per loop so that every loop lands in the fast phase, and verifies it in the disassembly.
+#define FT_LOOP_PHASE() asm volatile(".p2align 6\n\t.rept 0\n\ts_nop 0\n\t.endr" ::: "memory")
 
-#define FT_STR2(x) #x
-#define FT_STR(x) FT_STR2(x)
-#define FT_PHASE_ASM(pad) asm volatile(".p2align 6\n\t.rept " FT_STR(pad) "\n\ts_nop 0\n\t.endr" ::: "memory")
-#define FT_LOOP_PAD_NEAR_ALT 14
-#define FT_LOOP_PHASE(near, alt) do { if (near) { if (alt) FT_PHASE_ASM(FT_LOOP_PAD_NEAR_ALT); else FT_PHASE_ASM(FT_LOOP_PAD_NEAR); } \
-                                      else FT_PHASE_ASM(FT_LOOP_PAD_FAR); } while (0)
-
-template <bool NEAR, bool ALT = false>
+template <bool NEAR>
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
     float si = si_;
     asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
-    FT_LOOP_PHASE(NEAR, ALT);
+    FT_LOOP_PHASE();
     for (; i + FT_UNROLL <= count; i += FT_UNROLL) {
         float4 prm[FT_UNROLL];
         float q[FT_UNROLL];
@@ -488,7 +476,6 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
 // Lean evaluator for scenes whose whole program is {fast sphere SMOOTH_RUN..., SMOOTH_FIN, SETLEAF}
 // (FtSceneDev.fastPath == 1, decided when the scene is flattened): the accumulator lives in a VGPR,
 // no value slots, no primitive switch — the kernel variant built on it needs far fewer registers.
-template <bool ALT>
 __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, const f3 p, const float* __restrict__ ldsC,
                                                        float& outD, uint32_t& outLeaf) {
     float acc = 0.0f;
@@ -500,7 +487,7 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
         const uint32_t op = in->op;
         if (op == FT_OP_SMOOTH_RUN) {
             const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
-            if (__builtin_expect(nearOk, 1)) acc = smooth_run_spheres_fast<true, ALT>(ldsC + in->data, in->count, in->f0, p, sum0);
+            if (__builtin_expect(nearOk, 1)) acc = smooth_run_spheres_fast<true>(ldsC + in->data, in->count, in->f0, p, sum0);
             else if (fastOk) acc = smooth_run_spheres_fast<false>(ldsC + in->data, in->count, in->f0, p, sum0);
             else {                                                     // exact loop (SdfForm.fs:77-80, :129)
                 acc = sum0;
@@ -751,6 +738,9 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 template <int VARIANT, bool EXT>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const bool clockWave = blockIdx.x == 0 && tid < 64u;              // this wave reports the shader clock it ran at (statistics only)
+    unsigned long long clkS = 0, clkR = 0;
+    if (clockWave) { clkS = clock64(); clkR = wall_clock64(); }
     float* sd = ft_lds + FT_C_COUNT * FT_BLOCK + tid;
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + (FT_C_COUNT + a.S.nSlots) * FT_BLOCK) + tid;
     float* ldsC = ft_lds + (FT_C_COUNT + 2u * a.S.nSlots) * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
@@ -805,7 +795,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 if (s.phase == PH_NZ) q.z = base.z + h;
             }
             float d; uint32_t leaf;
-            if (VARIANT == 1 || VARIANT == 3) ft_eval_smooth_spheres<VARIANT == 3>(a.S, q, ldsC, d, leaf);
+            if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
             else ft_eval<VARIANT == 2>(a.S, q, sd, sl, ldsC, d, leaf);
             ft_count(FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
@@ -881,6 +871,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         if (ex) atomicAdd(&a.stats->rays_ext, ex);
         atomicAdd(&a.stats->wave_evals, (unsigned long long)waveEvals);
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
+        if (clockWave) { atomicAdd(&a.stats->clk_shader, clock64() - clkS); atomicAdd(&a.stats->clk_ref, wall_clock64() - clkR); }
     }
 }
 
@@ -891,9 +882,6 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_sp
 // EXTENSION builds of both (spp > 1 and / or ambient occlusion); the reference path never pays for them
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_ext(const FtRenderArgs a) { ft_trace_body<0, true>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_ext(const FtRenderArgs a) { ft_trace_body<1, true>(a); }
-// the lean variant with the other loop-placement parity (see FT_LOOP_PHASE); the host picks per context
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_alt(const FtRenderArgs a) { ft_trace_body<3, false>(a); }
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_alt_ext(const FtRenderArgs a) { ft_trace_body<3, true>(a); }
 // general scenes whose unions have combinator children evaluated on demand (FT_PR_CALL, FtSceneDev.fastPath == 2)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
@@ -1103,12 +1091,32 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (kept in this translation unit so the C ABI file is plain C++)
 // ------------------------------------------------------------------------------------------------
+#ifdef FT_EXPERIMENT
+// Diagnostic build only (`make experiment`, tools/asm_variants*.py): the lean kernel can be replaced at run time by the same
+// kernel from a re-assembled code object, so that edits of its machine code (instruction placement) can be timed.
+#include <hip/hip_runtime_api.h>
+static hipModule_t ft_exp_module = nullptr;
+static hipFunction_t ft_exp_fn = nullptr;
+extern "C" int ft_debug_set_hsaco(const char* path) {
+    if (ft_exp_module) { (void)hipModuleUnload(ft_exp_module); ft_exp_module = nullptr; ft_exp_fn = nullptr; }
+    if (!path || !*path) return 0;
+    if (hipModuleLoad(&ft_exp_module, path) != hipSuccess) return -1;
+    if (hipModuleGetFunction(&ft_exp_fn, ft_exp_module, "ft_trace_kernel_smooth_spheres") != hipSuccess) return -2;
+    return 0;
+}
+#endif
 extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
     const bool ext = a->ext != 0u;
-    const unsigned v = a->S.fastPath;                                  // 0 general, 1 lean smooth-sphere, 2 general with call children
-    if (v == 1 && a->leanAlt && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_alt_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
-    else if (v == 1 && a->leanAlt) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_alt, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
-    else if (v == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+    const unsigned v = a->S.fastPath;
+#ifdef FT_EXPERIMENT
+    if (v == 1 && !ext && ft_exp_fn) {
+        FtRenderArgs args = *a;
+        size_t size = sizeof(args);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(ft_exp_fn, blocks, 1, 1, FT_BLOCK, 1, 1, (unsigned)ldsBytes, st, nullptr, extra);
+    }
+#endif                                  // 0 general, 1 lean smooth-sphere, 2 general with call children
+    if (v == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (v == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (v == 2 && ext) hipLaunchKernelGGL(ft_trace_kernel_calls_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (v == 2) hipLaunchKernelGGL(ft_trace_kernel_calls, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Build step: machine-code placement of the sphere loops of the trace kernels.
+
+Measured on gfx950 (tools/asm_variants*.py, tools/pad_sweep.py; profiles/r02_*): the 4-children-per-trip loops of
+smooth_run_spheres_fast consist of ~72 four-byte instructions (distances, square roots) followed by ONE run of ~38
+64-bit encoded VALU instructions (the exp part).  When that run starts on an 8-byte boundary a C3 frame takes 0.1477 G
+shader cycles, when it starts at 4 mod 8 it takes 0.1377 G (-7 %) — the same on every MI355X tried; which of the two a
+plain compile produces is a lottery of the preceding code (a one-dword change flips it).  This pass removes the lottery:
+every loop is preceded (kernels.hip FT_LOOP_PHASE) by `.p2align 6` + `.rept N` s_nops; the pass assembles the device
+assembly, disassembles it, finds every such loop and sets N to 0 or 1 so that the loop's longest run of 64-bit VALU
+instructions starts at 4 mod 8, and verifies the result.
+
+    loop_layout.py fix  in.s out.s      (Makefile: between `hipcc -S --cuda-device-only` and the assembler)
+    loop_layout.py check kernels.o      (exit status 1 if a loop of a trace kernel is in the slow phase)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get("FT_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+ARCH = os.environ.get("FT_ARCH", "gfx950")
+MARK = "ft_loop_pad_"
+
+
+def disassemble(obj):
+    return subprocess.check_output([LLVM + "/llvm-objdump", "-d", obj], text=True)
+
+
+def device_code_object(path, tmp):
+    """the gfx950 code object hipcc embedded in a host object / shared library (offload bundle in .hip_fatbin)"""
+    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+    subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path, os.path.join(tmp, "unused")])
+    listing = subprocess.run([LLVM + "/clang-offload-bundler", "--list", "--type=o", "--input=" + fat], capture_output=True, text=True).stdout
+    target = next((t for t in listing.split() if ARCH in t), None)
+    if target is None:
+        raise SystemExit(f"{path}: no {ARCH} code object inside")
+    subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=" + target, "--input=" + fat, "--output=" + co])
+    return co
+
+
+def sphere_loops(dis):
+    """[(symbol, kind, [(address, size, text)])]: every backward-branch loop that holds exactly 4 v_rsq_f32"""
+    out, sym, ins = [], None, []
+
+    def flush():
+        for addr, _, text in ins:
+            m = re.match(r"s_cbranch_scc\d (\d+)", text)
+            if not m:
+                continue
+            off = int(m.group(1))
+            off = off - 65536 if off >= 32768 else off
+            if off >= 0:
+                continue
+            target = addr + 4 + 4 * off
+            body = [i for i in ins if target <= i[0] <= addr]
+            if sum(1 for i in body if i[2].startswith("v_rsq_f32")) == 4:
+                out.append((sym, "near" if any(i[2].startswith("v_lshl_add_u32") for i in body) else "far", body))
+
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([\w.$]+)>:", line)
+        if m:
+            if not m.group(1).startswith(MARK):                # analysis labels do not end a function
+                flush()
+                sym, ins = m.group(1), []
+            continue
+        m = re.match(r"\s+(\S.*?)\s+// ([0-9A-F]+): ((?:[0-9A-F]{8} ?)+)", line)
+        if m and sym:
+            ins.append((int(m.group(2), 16), 4 * len(m.group(3).split()), m.group(1)))
+    flush()
+    return out
+
+
+def longest_run(body):
+    best, cur = [], []
+    for i in body + [(0, 0, "")]:
+        if i[1] == 8 and i[2].startswith("v_"):
+            cur.append(i)
+        else:
+            if len(cur) > len(best):
+                best = cur
+            cur = []
+    return best
+
+
+def run_phase(body):
+    run = longest_run(body)
+    return run[0][0] % 8, run
+
+
+def assemble(lines, tmp, name):
+    s, o, co = (os.path.join(tmp, name + ext) for ext in (".s", ".o", ".co"))
+    open(s, "w").write("\n".join(lines) + "\n")
+    subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + ARCH, "-c", s, "-o", o])
+    subprocess.check_call([LLVM + "/ld.lld", "-shared", o, "-o", co])
+    return co
+
+
+def fix(src, dst):
+    lines = open(src).read().splitlines()
+    marks = [i for i, l in enumerate(lines) if re.match(r"\s*\.rept \d+\s*$", l) and i > 0 and lines[i - 1].strip() == ".p2align 6"]
+    if not marks:
+        raise SystemExit("loop_layout: no FT_LOOP_PHASE marker in the assembly")
+    pads = [0] * len(marks)
+
+    def render(with_labels):
+        out = list(lines)
+        for j, i in enumerate(marks):
+            out[i] = f"\t.rept {pads[j]}"
+        if with_labels:                                        # a symbol per marker: where it landed (objdump -t)
+            for j, i in reversed(list(enumerate(marks))):
+                out.insert(i - 1, f"{MARK}{j}:")
+        return out
+
+    with tempfile.TemporaryDirectory() as tmp:
+        for attempt in range(3):
+            co = assemble(render(True), tmp, "probe")
+            symtab = subprocess.check_output([LLVM + "/llvm-objdump", "-t", co], text=True)
+            where = {int(m.group(2)): int(m.group(1), 16) for m in re.finditer(r"^([0-9a-f]+) .*\b" + MARK + r"(\d+)$", symtab, re.M)}
+            loops = sphere_loops(disassemble(co))
+            slow = []
+            for sym, kind, body in loops:
+                phase, run = run_phase(body)
+                owner = max((j for j, a in where.items() if a <= body[0][0]), key=lambda j: where[j], default=None)
+                if owner is None or body[0][0] - where[owner] > 256:
+                    raise SystemExit(f"loop_layout: the {kind} loop at {body[0][0]:#x} of {sym} has no FT_LOOP_PHASE marker in front of it")
+                if phase != 4:
+                    slow.append(owner)
+            if not slow:
+                break
+            if attempt == 2 or len(set(slow)) != len(slow):
+                raise SystemExit("loop_layout: could not place every loop in the fast phase")
+            for j in slow:
+                pads[j] ^= 1
+        final = render(False)
+        co = assemble(final, tmp, "final")
+        report = []
+        for sym, kind, body in sphere_loops(disassemble(co)):
+            phase, run = run_phase(body)
+            report.append(f"{sym}: {kind} loop {len(body)} instr / {body[-1][0] + 4 - body[0][0]} B, 64-bit run of {len(run)} at {run[0][0]:#x} = {phase} mod 8")
+            if phase != 4:
+                raise SystemExit("loop_layout: verification failed: " + report[-1])
+    open(dst, "w").write("\n".join(final) + "\n")
+    print(f"loop_layout: {len(report)} sphere loops placed in the fast phase (pads {pads})")
+    return report
+
+
+def check(path, only_trace_kernels=True):
+    with tempfile.TemporaryDirectory() as tmp:
+        co = device_code_object(path, tmp) if not path.endswith((".co", ".hsaco")) else path
+        bad = n = 0
+        for sym, kind, body in sphere_loops(disassemble(co)):
+            if only_trace_kernels and not sym.startswith("ft_trace_kernel"):
+                continue
+            phase, run = run_phase(body)
+            n += 1
+            bad += phase != 4
+            print(f"{sym}: {kind} loop at {body[0][0]:#x} ({len(body)} instructions, {body[-1][0] + 4 - body[0][0]} bytes), longest 64-bit VALU run = "
+                  f"{len(run)} instructions at {run[0][0]:#x} = {phase} mod 8 -> {'fast' if phase == 4 else 'SLOW'} phase")
+    if n == 0:
+        raise SystemExit("loop_layout: no sphere loop found: the check needs updating")
+    return bad
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "fix":
+        fix(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) == 3 and sys.argv[1] == "check":
+        sys.exit(1 if check(sys.argv[2]) else 0)
+    else:
+        raise SystemExit(__doc__)

@@ -163,6 +163,7 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
             stats->hits_primary += sts[r].hits_primary; stats->hits_shadow += sts[r].hits_shadow; stats->sdf_evals += sts[r].sdf_evals;
             stats->flags |= sts[r].flags; stats->wave_evals += sts[r].wave_evals;
             if (sts[r].kernel_ms > stats->kernel_ms) stats->kernel_ms = sts[r].kernel_ms;   // devices run concurrently
+            if (r == 0 || sts[r].shader_mhz < stats->shader_mhz) stats->shader_mhz = sts[r].shader_mhz;   // the slowest clock
         }
     }
     return FT_OK;

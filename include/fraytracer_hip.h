@@ -87,8 +87,11 @@ typedef struct ft_stats {         /* filled per call; all counts are exact */
     uint64_t sdf_evals;           /* scene-SDF evaluations (march steps + normal probes) */
     uint64_t flags;               /* bit0 NaN distance met, bit2 step cap hit (reference would not terminate) */
     float kernel_ms;              /* HIP-event time of the render kernel(s) of this call */
-    float reserved;               /* diagnostic: placement variant of the lean smooth-sphere kernel this context uses (-1, 0, 1) */
+    float reserved;
     uint64_t wave_evals;          /* wave-level evaluation rounds: sdf_evals / (64 * wave_evals) = lane utilisation */
+    float shader_mhz;             /* shader clock the render kernel(s) of this call ran at: s_memtime ticks / s_memrealtime ticks
+                                   * (constant 100 MHz) of one wave that lives as long as the kernel; 0 if unknown */
+    float reserved2;
 } ft_stats;
 
 /* ---- context ------------------------------------------------------------------------ */

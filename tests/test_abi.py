@@ -34,7 +34,7 @@ def test_blittable_layouts_match_the_reference_records():
     # Types.fs:9-24 Ray 32 B / SdfBoundary 16 B; Camera.fs:16-22 48 B; primitive structs SdfForm.fs:118-212
     assert C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Boundary) == 16 and C.sizeof(_lib.CameraS) == 48
     assert C.sizeof(_lib.Sphere) == 16 and C.sizeof(_lib.Capsule) == 28 and C.sizeof(_lib.Torus) == 32 and C.sizeof(_lib.Triangle) == 40
-    assert C.sizeof(_lib.RenderParams) == 56 and C.sizeof(_lib.Stats) == 72
+    assert C.sizeof(_lib.RenderParams) == 56 and C.sizeof(_lib.Stats) == 80
     assert _lib.lib.ft_abi_version() == 3
 
 
@@ -69,7 +69,7 @@ int main(void) {
     O(ft_render_params, x0); O(ft_render_params, stripe_width); O(ft_render_params, spp); O(ft_render_params, epsilon);
     O(ft_render_params, length); O(ft_render_params, ao_samples); O(ft_render_params, ao_radius); O(ft_render_params, max_bounces);
     O(ft_render_params, spectral);
-    O(ft_stats, hits_primary); O(ft_stats, sdf_evals); O(ft_stats, flags); O(ft_stats, kernel_ms); O(ft_stats, reserved); O(ft_stats, wave_evals);
+    O(ft_stats, hits_primary); O(ft_stats, sdf_evals); O(ft_stats, flags); O(ft_stats, kernel_ms); O(ft_stats, reserved); O(ft_stats, wave_evals); O(ft_stats, shader_mhz);
     O(ft_tonemap_params, gamma); O(ft_tonemap_params, dither); O(ft_tonemap_params, seed); O(ft_tonemap_params, bmp_order);
     return 0;
 }
@@ -92,7 +92,7 @@ def test_header_is_plain_c99_with_the_reference_layouts(tmp_path):
         got[(kind, name)] = int(val)
     want_sizes = {"ft_vec3": 12, "ft_ray": 32, "ft_boundary": 16, "ft_form_trace_result": 40, "ft_object_trace_result": 64,
                   "ft_sphere": 16, "ft_capsule": 28, "ft_torus": 32, "ft_triangle": 40, "ft_box": 24, "ft_camera": 48,
-                  "ft_render_params": 56, "ft_stats": 72, "ft_scene_info": 40, "ft_handle": 4, "ft_tonemap_params": 16}
+                  "ft_render_params": 56, "ft_stats": 80, "ft_scene_info": 40, "ft_handle": 4, "ft_tonemap_params": 16}
     for k, v in want_sizes.items():
         assert got[("sizeof", k)] == v, (k, got[("sizeof", k)], v)
     want_offsets = {"ft_ray.direction": 12, "ft_ray.length": 24, "ft_ray.epsilon": 28, "ft_boundary.radius": 12,
@@ -105,7 +105,7 @@ def test_header_is_plain_c99_with_the_reference_layouts(tmp_path):
                     "ft_render_params.epsilon": 32, "ft_render_params.length": 36, "ft_render_params.ao_samples": 40,
                     "ft_render_params.ao_radius": 44, "ft_render_params.max_bounces": 48, "ft_render_params.spectral": 52,
                     "ft_stats.hits_primary": 24, "ft_stats.sdf_evals": 40, "ft_stats.flags": 48, "ft_stats.kernel_ms": 56,
-                    "ft_stats.reserved": 60, "ft_stats.wave_evals": 64,
+                    "ft_stats.reserved": 60, "ft_stats.wave_evals": 64, "ft_stats.shader_mhz": 72,
                     "ft_tonemap_params.gamma": 0, "ft_tonemap_params.dither": 4, "ft_tonemap_params.seed": 8,
                     "ft_tonemap_params.bmp_order": 12}
     for k, v in want_offsets.items():

@@ -505,31 +505,21 @@ def test_unions_of_many_combinator_children(gpu, oracle):
     assert_bit_equal(g, o, "same, extension kernel")
 
 
-def test_lean_kernel_placement_variants_agree(oracle):
-    """the lean smooth-sphere kernel exists with two placements of its inner loop (which one is faster differs
-    between boxes; a context times both on its first large frame): both, and the automatic choice, give the
-    oracle's image bit for bit"""
-    import os
+def test_lean_kernel_at_2_pow_20_jobs_against_oracle(gpu, oracle):
+    """the shape-specialised smooth-sphere kernel (whose inner loops the build's layout pass places, csrc/loop_layout.py) on a
+    frame of 2^20 jobs, plain and 4-spp EXTENSION build: sampled columns against the oracle, counters exact"""
     scene, _ = syn.config3(n=64, size=1024)
     cam = syn.default_camera()
-    frames = []
-    for force in ("0", "1", None):
-        if force is None: os.environ.pop("FT_LEAN_ALT", None)
-        else: os.environ["FT_LEAN_ALT"] = force
-        try:
-            dev = ft.Device(0)
-            img, st = dev.scene(scene).render(EPS, LEN, ft.ImageSize(1024, 1024), cam)        # 2^20 jobs: the choice is made here
-            img2, st2 = dev.scene(scene).render(EPS, LEN, ft.ImageSize(1024, 1024), cam, spp=4)   # EXTENSION build chooses separately
-            assert st["rays_primary"] == 1024 * 1024 and st2["rays_primary"] == 4 * 1024 * 1024     # calibration launches are not counted
-            frames.append((img, img2))
-            dev.close()
-        finally:
-            os.environ.pop("FT_LEAN_ALT", None)
-    for a, b in frames[1:]:
-        assert_bit_equal(a, frames[0][0], "placement variants, 1 spp")
-        assert_bit_equal(b, frames[0][1], "placement variants, 4 spp")
-    want, _ = oracle.Oracle().scene(scene).render(EPS, LEN, 1024, 1024, cam.as_array(), x0=500, x1=516)
-    assert_bit_equal(frames[0][0][500:516], want, "against the oracle")
+    ds, os_ = both(gpu, oracle, scene)
+    assert ds.info()["fast_path"] == 1
+    img, st = ds.render(EPS, LEN, ft.ImageSize(1024, 1024), cam)
+    img4, st4 = ds.render(EPS, LEN, ft.ImageSize(1024, 1024), cam, spp=4)
+    assert st["rays_primary"] == 1024 * 1024 and st4["rays_primary"] == 4 * 1024 * 1024
+    want, _ = os_.render(EPS, LEN, 1024, 1024, cam.as_array(), x0=500, x1=516)
+    assert_bit_equal(img[500:516], want, "1 spp against the oracle")
+    want4, _ = os_.render(EPS, LEN, 1024, 1024, cam.as_array(), x0=500, x1=516, spp=4)
+    assert_bit_equal(img4[500:516], want4, "4 spp against the oracle")
+    assert st["shader_mhz"] > 500.0                      # the kernel reports the shader clock it ran at
 
 
 def test_nan_distances_are_flagged_identically(gpu, oracle):
