@@ -42,6 +42,16 @@ def algorithmic_flops(stats, n_children, flops_per_child=13, flops_per_eval=3):
     return evals * (n_children * flops_per_child + flops_per_eval) + 8 * steps + 20 * normals + 25 * stats["rays_shadow"]
 
 
+def union_algorithmic_flops(cnt):
+    """SURVEY.md section 8d pricing of a grid-union scene from the oracle's counters (the reference's own work: it scans a
+    cell's whole candidate list): primitives sphere 10 / capsule 21 / torus 27 / triangle 87 / box 20, union 13 per candidate
+    + 30 per lookup (one per scene evaluation), intersect 12 + subtract 2 per evaluation of the Program.fs structure,
+    8 per march step, 20 per normal, 25 per shadow ray."""
+    prim = cnt["prim"]
+    return (10 * prim[0] + 21 * prim[1] + 27 * prim[2] + 87 * prim[3] + 20 * prim[4] + 13 * cnt["union_candidates"]
+            + (30 + 12 + 2) * cnt["root_evals"] + 8 * cnt["march_steps"] + 20 * cnt["hits_primary"] + 25 * cnt["rays_shadow"])
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, tools/profile.sh).  FETCH_SIZE is doubled as the
@@ -69,7 +79,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="frame is size x size (default: the metric's 4096)")
     ap.add_argument("--spheres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-spp4", action="store_true", help="skip the 4-samples-per-pixel (extension) timing of the same frame")
+    ap.add_argument("--no-side", "--no-spp4", dest="no_spp4", action="store_true",
+                    help="skip the side measurements (4 spp, two lanes, host output, primary + AO target, Program.fs scene)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
     ap.add_argument("--cpu-columns", type=int, default=0,
@@ -144,7 +155,7 @@ def main():
             return lambda dst: d.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, dst.data_ptr(), **tiling)
 
         pipe = ftd.FramePipeline([lane(d) for d in lanes], cols, H, world, rank, STRIPE, torch.device("cuda", local_rank),
-                                 streams=lane_streams, force=args.force_dist)
+                                 streams=lane_streams, force=args.force_dist, timed=True)
 
     def collect():
         """exact counters + HIP-event kernel time since the last call, summed over the render lanes"""
@@ -174,6 +185,8 @@ def main():
         step()
     fence()
     collect()                                     # drop warm-up counters / events
+    if pipe is not None:
+        pipe.timings()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -230,11 +243,75 @@ def main():
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr())          # slab = the 1-spp frame of `ds` again
         torch.cuda.synchronize(); ds.collect_stats()
 
+
+    # Image.render returns a HOST FColor[,] (Image.fs:26-35): the same K frames through ft_render into a page-locked host
+    # array (ft_host_register) — four column chunks on two streams, every finished chunk copied behind the rendering.
+    host_out = None
+    if world == 1 and pipe is None and not args.no_spp4:
+        host = np.zeros((W, H, 3), np.float32)
+        dev.host_register(host)
+        ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, out=host)
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            _, hst = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, out=host)
+        dth = time.perf_counter() - th
+        same = bool(np.array_equal(host.view(np.uint32), slab.cpu().numpy().view(np.uint32)))
+        dev.host_unregister(host)
+        host_out = {"value": round((hst["rays_primary"] + hst["rays_shadow"]) * args.steps / dth / 1e6, 3), "unit": "Mrays/s",
+                    "ms_per_step": round(dth / args.steps * 1e3, 3), "identical_to_device_frame": same,
+                    "note": "ft_render: frame delivered in host memory (201 MB over PCIe per 4096^2 frame), destination page-locked "
+                            "once; 4 column chunks on 2 streams, copies overlap the rendering"}
+        del host
+
+    # The north star's target: primary + ambient-occlusion rays at 4096^2 on the 256-op scene (EXTENSION: the reference has
+    # no AO; 4 rays of radius 0.5 per primary hit), and the reference's own workload, Program.fs:14-83, at 4000^2.
+    target = None
+    console = None
+    if world == 1 and pipe is None and not args.no_spp4 and W == 4096:
+        kw = dict(ao_samples=4, ao_radius=0.5)
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **kw)
+        torch.cuda.synchronize(); ds.collect_stats()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **kw)
+        torch.cuda.synchronize()
+        dta = time.perf_counter() - ta
+        sa = ds.collect_stats()
+        rays_a = sa["rays_primary"] + sa["rays_shadow"] + sa["rays_ext"]
+        target = {"value": round(rays_a / dta / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dta / args.steps * 1e3, 3),
+                  "primary": sa["rays_primary"] // args.steps, "ao": sa["rays_ext"] // args.steps, "shadow": sa["rays_shadow"] // args.steps,
+                  "kernel": "ft_trace_kernel_smooth_spheres_ext", "target": ">= 100 Mrays/s primary+AO at 4096^2, 256 SDF ops, >= 40 % VALU-busy",
+                  "note": "EXTENSION (no reference counterpart): C3 scene, 1 spp, 4 AO rays of radius 0.5 per primary hit; rays = primary + AO + shadow"}
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr())
+        torch.cuda.synchronize(); ds.collect_stats()
+
+        cscene, _ = syn.console_scene()
+        cds = dev.scene(cscene)
+        CW = 4000
+        csize = ft.ImageSize(CW, CW)
+        cbuf = torch.empty((CW, CW, 3), dtype=torch.float32, device="cuda")
+        cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
+        torch.cuda.synchronize(); cds.collect_stats()
+        for _ in range(args.steps):
+            cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
+        torch.cuda.synchronize()
+        cst = cds.collect_stats()
+        console = {"stats": cst, "frame": cbuf, "scene": cscene, "W": CW}
+
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"]],
                        dtype=torch.int64, device="cuda")
     kms = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device="cuda")
+    per_rank = None
     if use_dist:
+        # a SCALE record should explain itself: every rank's kernel time, shader clock, gather and de-interleave time per frame
+        g_ms, d_ms = pipe.timings()
+        mine = torch.tensor([st["kernel_ms"] / args.steps, st["shader_mhz"], g_ms / args.steps, d_ms / args.steps, dt / args.steps * 1e3],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "kernel_ms": round(float(v[0]), 3), "shader_mhz": round(float(v[1]), 1), "gather_ms": round(float(v[2]), 3),
+                     "deinterleave_ms": round(float(v[3]), 3), "ms_per_step": round(float(v[4]), 3)} for r, v in enumerate(allr)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
@@ -251,7 +328,8 @@ def main():
         launch_s = st["kernel_ms"] / 1e3 / args.steps
         achieved = flops_launch / launch_s / 1e12
         out = {
-            "metric": "Mrays/s (primary+secondary) at 4096x4096; max per-pixel |delta| vs F# ref",
+            "metric": "Mrays/s (primary+secondary) at 4096x4096; max per-pixel |delta| vs F# ref "
+                      "(delta is measured against the CPU oracle: F# parity is unpinned, DESIGN.md section 2)",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -261,17 +339,26 @@ def main():
                        "shadow": rays_shadow // args.steps, "sdf_evals_per_frame": evals // args.steps,
                        "parallelism": f"column stripes of {STRIPE} over {world} GPU(s) + 1 RCCL gather" if world > 1 else "1 GPU",
                        "nan_or_cap_flags": flags,
-                       "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4)},
+                       "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4),
+                       "shader_mhz": round(st["shader_mhz"], 1)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "valu_busy_pmc": valu_busy,
                          "kernel": "ft_trace_kernel_smooth_spheres",
                          "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
+                         "shader_mhz": round(st["shader_mhz"], 1),
+                         "shader_Gcycles_per_launch": round(launch_s * st["shader_mhz"] * 1e6 / 1e9, 4),
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
                                  "flop each although a correctly rounded sqrt / reproducible exp need 5 / 11 instructions "
-                                 "(DESIGN.md section 5: ~93 % of the instruction-issue bound). HBM traffic = 12 B/pixel output."},
+                                 "(DESIGN.md section 5: at the instruction-issue floor of this mix). peak is priced at 2.4 GHz; the chip "
+                                 "sustains shader_mhz under this load (power management), which is the box-to-box spread. "
+                                 "HBM traffic = 12 B/pixel output."},
         }
+        if per_rank is not None:
+            out["config"]["per_rank"] = per_rank
+            out["config"]["per_rank_note"] = ("per frame: kernel_ms = mean start-to-end time of this rank's launches (two overlapping lanes), gather_ms = "
+                                              "the RCCL gather on the side stream incl. waiting for the slowest rank, deinterleave_ms = rank 0's strided copy")
         if pipe is not None:
             out["roofline"]["launch_overlap"] = ("consecutive frames run on two streams and overlap: kernel_ms is the mean start-to-end "
                                                  "time of a launch, not its exclusive time; frames per second come from ms_per_step")
@@ -279,14 +366,50 @@ def main():
             out["config"]["same_frame_at_4_spp"] = spp4
         if streamed is not None:
             out["config"]["frames_streamed_on_two_lanes"] = streamed
+        if host_out is not None:
+            out["config"]["host_output"] = host_out
+        if target is not None:
+            out["config"]["north_star_target"] = target
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab if pipe is None else pipe.frame)
             out["config"]["max_abs_delta_vs_oracle"] = check["max_abs_delta"]      # second half of the metric: 0.0 = bit-exact
             out["config"]["pixels_compared_with_oracle"] = check["pixels"]
+            if console is not None:
+                out["config"]["program_fs_scene"] = program_fs_block(console, cam, args.steps)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def program_fs_block(console, cam, steps):
+    """Side block for the reference's own workload (src/FrayTracer.Console/Program.fs:14-83: System.Random(19), 1000 tori,
+    subtract(intersect(union, sphere), sphere), 2 lights) at 4000^2 on the general grid-union kernel: Mrays/s, and its own
+    roofline entry priced as SURVEY.md section 8d prescribes for unions, with the oracle's counters of a column sample of the same
+    frame (the per-evaluation flop count is scaled by the kernel's exact evaluation count); the sampled columns are compared."""
+    import numpy as np
+    from oracle import binding as ob
+    cst, CW = console["stats"], console["W"]
+    xstep = 40
+    osc = ob.Oracle().scene(console["scene"])
+    img, cnt = osc.render(0.01, 30.0, CW, CW, cam.as_array(), xstep=xstep, nthreads=host_cpu_share())
+    got = console["frame"][::xstep].cpu().numpy()
+    delta = float(np.max(np.abs(got.astype(np.float64) - img.astype(np.float64))))
+    flops_per_eval = union_algorithmic_flops(cnt) / max(1, cnt["root_evals"])
+    evals = cst["sdf_evals"] / steps
+    kernel_s = cst["kernel_ms"] / 1e3 / steps
+    rays = (cst["rays_primary"] + cst["rays_shadow"]) / steps
+    achieved = flops_per_eval * evals / kernel_s / 1e12
+    return {"workload": f"Program.fs scene, {CW}x{CW}, 1 spp, directional + point light", "value": round(rays / kernel_s / 1e6, 1), "unit": "Mrays/s",
+            "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals),
+            "lane_utilisation": round(cst["sdf_evals"] / (64.0 * max(1, cst["wave_evals"])), 4), "shader_mhz": round(cst["shader_mhz"], 1),
+            "max_abs_delta_vs_oracle": delta, "pixels_compared_with_oracle": int(img.shape[0] * img.shape[1]),
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "algorithmic_flops_per_eval": round(flops_per_eval, 1),
+                         "candidates_per_eval_reference": round(cnt["union_candidates"] / max(1, cnt["root_evals"]), 2),
+                         "primitive_evals_per_eval": round(sum(cnt["prim"]) / max(1, cnt["root_evals"]), 2),
+                         "note": "the reference scans a cell's whole candidate list (13 flops per candidate); the kernel leaves the sorted "
+                                 "list at the first failing LowerBound test (exact), so it executes fewer than the priced operations"}}
 
 
 def host_cpu_share():

@@ -120,6 +120,8 @@ SYMBOLS = {
     "ft_lens_create": (C.c_float, [C.c_float]),
     "ft_camera_look_at": (C.c_int, [_F3, _F3, _F3, C.c_float, C.POINTER(CameraS)]),
     "ft_render": (C.c_int, [_P, _P, C.POINTER(CameraS), C.POINTER(RenderParams), _P, C.POINTER(Stats)]),
+    "ft_host_register": (C.c_int, [_P, _P, C.c_uint64]),
+    "ft_host_unregister": (C.c_int, [_P, _P]),
     "ft_render_device": (C.c_int, [_P, _P, C.POINTER(CameraS), C.POINTER(RenderParams), _P]),
     "ft_collect_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "ft_tone_map_device": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(TonemapParams), _P]),

@@ -344,6 +344,13 @@ class Device:
             lib.ft_ctx_destroy(self._ctx)
             self._ctx = None
 
+    def host_register(self, array):
+        """page-lock a numpy array that is reused as render(..., out=array) destination (ft_host_register)"""
+        check(lib.ft_host_register(self._ctx, array.ctypes.data_as(C.c_void_p), array.nbytes))
+
+    def host_unregister(self, array):
+        check(lib.ft_host_unregister(self._ctx, array.ctypes.data_as(C.c_void_p)))
+
     def set_stream(self, hip_stream):
         check(lib.ft_ctx_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
@@ -453,10 +460,14 @@ class DeviceScene:
                                  int(spp), float(epsilon), float(length), int(ao_samples), float(ao_radius),
                                  int(max_bounces), int(spectral))
 
-    def render(self, epsilon, length, imageSize, camera, **tiling):
-        """Image.render (Image.fs:26-35) -> (FColor[X,Y] as float32 [n_columns, Y, 3], stats dict)."""
+    def render(self, epsilon, length, imageSize, camera, out=None, **tiling):
+        """Image.render (Image.fs:26-35) -> (FColor[X,Y] as float32 [n_columns, Y, 3], stats dict).  `out`: a float32 array
+        of that shape to render into (e.g. one page-locked with Device.host_register)."""
         p = self._params(imageSize, epsilon, length, **tiling)
-        out = np.empty((p.n_columns, p.height, 3), np.float32)
+        if out is None:
+            out = np.empty((p.n_columns, p.height, 3), np.float32)
+        elif out.dtype != np.float32 or out.shape != (p.n_columns, p.height, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape (n_columns, Y, 3)")
         st = _lib.Stats()
         check(lib.ft_render(self.device._ctx, self._scene, C.byref(camera._c), C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
         return out, st.as_dict()

@@ -39,6 +39,9 @@ struct ft_ctx {
     void* scratch = nullptr; size_t scratchBytes = 0;     // staging for host-output entry points
     void* planes = nullptr; size_t planesBytes = 0;       // EXTENSION spp > 1: per-sample frames before the resolve
     void* aux = nullptr; size_t auxBytes = 0;             // tone map: [256 B: max bits | 8-bit image]
+    hipStream_t lane1 = nullptr, copyStream = nullptr;    // ft_render's host-output pipeline: second render lane, DMA stream (lazily created)
+    std::vector<hipEvent_t> syncEvents;                   // untimed events of that pipeline
+    std::vector<std::pair<void*, size_t>> hostRegs;       // ranges pinned through ft_host_register
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect (at most FT_MAX_PENDING_EVENTS)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
     double foldedMs = 0.0;                                 // kernel time of launches whose event pair was already recycled
@@ -205,7 +208,11 @@ int acquireEvents(ft_ctx* c, hipEvent_t& a, hipEvent_t& b) {
 }
 
 // launch the persistent trace kernel over nJobs jobs
-int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
+// lane 0 = the context's stream; lane 1 = a second stream with its own job counter, so that two launches can be in flight
+// (the drain of one overlaps the start of the next: DESIGN.md section 6)
+int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
+    hipStream_t stream = lane ? c->lane1 : c->stream;
+    uint32_t* counter = c->dCounter + (lane ? 16 : 0);
     int perCU = 0;
     HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, ldsBytes(s), &perCU));
     perCU = std::max(1, std::min(perCU, 8));
@@ -216,17 +223,17 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a) {
     // one 8x8 tile per grab: measured faster than larger chunks (lanes of a wave stay on neighbouring
     // pixels) and 2.6e5 atomics per 4096^2 frame are far below the rate one counter sustains
     a.chunk = 64;
-    a.counter = c->dCounter;
+    a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
     a.materialsExt = s->dMaterialsExt;
-    HIP_TRY(hipMemsetAsync(c->dCounter, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
     hipEvent_t e0, e1;
     int rc = foldOldestEvents(c); if (rc) return rc;
     if ((rc = acquireEvents(c, e0, e1))) return rc;
-    HIP_TRY(hipEventRecord(e0, c->stream));
-    HIP_TRY(ft_launch_trace(&a, blocks, ldsBytes(s), c->stream));
-    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventRecord(e0, stream));
+    HIP_TRY(ft_launch_trace(&a, blocks, ldsBytes(s), stream));
+    HIP_TRY(hipEventRecord(e1, stream));
     c->events.emplace_back(e0, e1);
     return FT_OK;
 }
@@ -297,6 +304,10 @@ void ft_ctx_destroy(ft_ctx* c) {
         if (c->scratch) (void)hipFree(c->scratch);
         if (c->planes) (void)hipFree(c->planes);
         if (c->aux) (void)hipFree(c->aux);
+        for (auto& r : c->hostRegs) (void)hipHostUnregister(r.first);
+        for (auto e : c->syncEvents) (void)hipEventDestroy(e);
+        if (c->lane1) { (void)hipStreamSynchronize(c->lane1); (void)hipStreamDestroy(c->lane1); }
+        if (c->copyStream) { (void)hipStreamSynchronize(c->copyStream); (void)hipStreamDestroy(c->copyStream); }
         if (c->dCounter) (void)hipFree(c->dCounter);
         if (c->dStats) (void)hipFree(c->dStats);
         if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -425,10 +436,11 @@ int ft_camera_look_at(const float pos[3], const float look[3], const float up[3]
 }
 
 // ---- hot path ------------------------------------------------------------------------------------
-int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, void* d_out) {
+static int renderLane(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, void* d_out, int lane) {
     int rc = requireDevice(c); if (rc) return rc;
     if (!s || s->ctx != c || !cam || !d_out) return setErr(FT_ERR_INVALID, "bad argument (scene must belong to this context)");
     if ((rc = checkParams(p))) return rc;
+    if (lane != 0 && p->spp != 1) return setErr(FT_ERR_INVALID, "internal: the sample planes belong to lane 0");
     FtRenderArgs a{};
     memcpy(a.cam, cam, sizeof(float) * 12);
     a.W = p->width; a.H = p->height; a.x0 = p->x0; a.nCols = p->n_columns;
@@ -447,7 +459,7 @@ int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const f
     a.spectral = (uint32_t)p->spectral;
     if (a.spectral) ft::spectralTable((int)a.spectral, a.spec);
     a.ext = (a.spp != 1u || a.aoSamples != 0u || a.maxBounces != 0u || a.spectral != 0u) ? 1u : 0u;
-    if (a.spp == 1) { a.out = static_cast<float*>(d_out); return launchTrace(c, s, a); }
+    if (a.spp == 1) { a.out = static_cast<float*>(d_out); return launchTrace(c, s, a, lane); }
     // EXTENSION: one frame per sample, then a fixed-order resolve
     const size_t planeFloats = (size_t)a.planePixels * 3;
     const size_t need = planeFloats * a.spp * sizeof(float);
@@ -460,6 +472,10 @@ int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const f
     if ((rc = launchTrace(c, s, a))) return rc;
     HIP_TRY(ft_launch_resolve(static_cast<const float*>(c->planes), static_cast<float*>(d_out), planeFloats, a.spp, c->stream));
     return FT_OK;
+}
+
+int ft_render_device(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, void* d_out) {
+    return renderLane(c, s, cam, p, d_out, 0);
 }
 
 int ft_collect_stats(ft_ctx* c, ft_stats* st) {
@@ -488,14 +504,104 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
     return FT_OK;
 }
 
+// ---- host output: Image.render returns a host FColor[,] (Image.fs:26-35) ------------------------------------------
+// The frame (12 B / pixel) has to cross PCIe.  A pageable destination is copied by the runtime through its own staging
+// at 4-8 GB/s (23-50 ms for a 4096^2 frame); a page-locked one is written by the DMA engines at link rate.  ft_render
+// therefore (a) page-locks the caller's buffer for the duration of the call unless it already is (ft_host_register, or
+// memory from hipHostMalloc) — the pinning runs on the calling thread while the GPU already renders — and (b) renders
+// a large contiguous frame in four column chunks on two alternating streams (the drain of one chunk overlaps the start of
+// the next) while a third stream copies every finished chunk, so that only the last chunk's copy is left at the end.
+int ft_host_register(ft_ctx* c, void* p, uint64_t bytes) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!p || bytes == 0) return setErr(FT_ERR_INVALID, "bad argument");
+    HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+    c->hostRegs.emplace_back(p, (size_t)bytes);
+    return FT_OK;
+}
+
+int ft_host_unregister(ft_ctx* c, void* p) {
+    int rc = requireDevice(c); if (rc) return rc;
+    for (size_t i = 0; i < c->hostRegs.size(); ++i)
+        if (c->hostRegs[i].first == p) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipHostUnregister(p));
+            c->hostRegs.erase(c->hostRegs.begin() + (long)i);
+            return FT_OK;
+        }
+    return setErr(FT_ERR_INVALID, "this pointer was not registered through ft_host_register");
+}
+
+namespace {
+
+bool isPageLocked(ft_ctx* c, const void* p, size_t bytes) {
+    const char* b = static_cast<const char*>(p);
+    for (auto& r : c->hostRegs)
+        if (b >= static_cast<const char*>(r.first) && b + bytes <= static_cast<const char*>(r.first) + r.second) return true;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: "invalid value"
+    return attr.type == hipMemoryTypeHost;
+}
+
+int ensurePipeline(ft_ctx* c, size_t nEvents) {
+    if (!c->lane1) HIP_TRY(hipStreamCreateWithFlags(&c->lane1, hipStreamNonBlocking));
+    if (!c->copyStream) HIP_TRY(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    while (c->syncEvents.size() < nEvents) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->syncEvents.push_back(e);
+    }
+    return FT_OK;
+}
+
+}  // namespace
+
 int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, float* out, ft_stats* st) {
     int rc = requireDevice(c); if (rc) return rc;
     if (!out) return setErr(FT_ERR_INVALID, "null output");
     if ((rc = checkParams(p))) return rc;
-    const size_t bytes = (size_t)p->n_columns * p->height * 3 * sizeof(float);
+    const size_t colBytes = (size_t)p->height * 3 * sizeof(float);
+    const size_t bytes = (size_t)p->n_columns * colBytes;
     if ((rc = ensureScratch(c, bytes))) return rc;
-    if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    char* dFrame = static_cast<char*>(c->scratch);
+    // chunks: only the reference's sampling (spp = 1: no shared sample planes) of a contiguous column range that is worth it
+    int nChunks = (p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 256 && bytes >= ((size_t)16 << 20)) ? 4 : 1;
+    if (const char* e = getenv("FT_HOST_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 8 * v) nChunks = v; }   // experiments
+    const bool wantPin = bytes >= ((size_t)1 << 20) && !getenv("FT_HOST_NO_PIN");
+    if ((rc = ensurePipeline(c, (size_t)nChunks + 2))) return rc;
+    hipEvent_t evStart = c->syncEvents[0], evCopied = c->syncEvents[1];
+    HIP_TRY(hipEventRecord(evStart, c->stream));               // whatever the caller queued on the context's stream comes first
+    HIP_TRY(hipStreamWaitEvent(c->lane1, evStart, 0));
+    HIP_TRY(hipStreamWaitEvent(c->copyStream, evStart, 0));
+    std::vector<int> c0(nChunks + 1);
+    for (int i = 0; i < nChunks; ++i) c0[i] = (int)(((int64_t)p->n_columns * i / nChunks) & ~(int64_t)7);   // chunks start on a tile boundary
+    c0[nChunks] = p->n_columns;
+    for (int i = 0; i < nChunks; ++i) {
+        ft_render_params q = *p;
+        q.x0 = p->x0 + c0[i]; q.n_columns = c0[i + 1] - c0[i];
+        if (p->stripe_ranks == 1) q.stripe_width = q.n_columns;
+        const int lane = nChunks > 1 ? (i & 1) : 0;
+        if ((rc = renderLane(c, s, cam, &q, dFrame + (size_t)c0[i] * colBytes, lane))) return rc;
+        HIP_TRY(hipEventRecord(c->syncEvents[2 + i], lane ? c->lane1 : c->stream));
+    }
+    // the GPU is rendering: page-lock the destination meanwhile
+    bool pinnedHere = false;
+    if (wantPin && !isPageLocked(c, out, bytes)) {
+        const hipError_t e = hipHostRegister(out, bytes, hipHostRegisterDefault);
+        if (e == hipSuccess) pinnedHere = true; else (void)hipGetLastError();    // not fatal: the runtime's pageable path still works
+    }
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < nChunks && err == hipSuccess; ++i) {
+        const size_t off = (size_t)c0[i] * colBytes, n = (size_t)(c0[i + 1] - c0[i]) * colBytes;
+        if ((err = hipStreamWaitEvent(c->copyStream, c->syncEvents[2 + i], 0)) != hipSuccess) break;
+        err = hipMemcpyAsync(reinterpret_cast<char*>(out) + off, dFrame + off, n, hipMemcpyDeviceToHost, c->copyStream);
+    }
+    if (err == hipSuccess) err = hipEventRecord(evCopied, c->copyStream);
+    if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, evCopied, 0);          // join: the context's stream ends after the copies
+    if (err == hipSuccess) err = hipStreamSynchronize(c->copyStream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->lane1);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    if (pinnedHere) (void)hipHostUnregister(out);
+    if (err != hipSuccess) return hipFail(err, "ft_render host output");
     return ft_collect_stats(c, st);
 }
 

@@ -37,23 +37,28 @@ def gather_buffers(slab, world, rank, force=False):
             torch.empty((cols * world, H, C), dtype=slab.dtype, device=slab.device))
 
 
-def gather_frame(slab, world, rank, stripe, frame=None, recv=None, group=None, force=False):
+def gather_frame(slab, world, rank, stripe, frame=None, recv=None, group=None, force=False, mark=None):
     """Collect the per-rank slabs [W/world, H, 3] on rank 0 and de-interleave them into the full
     [W, H, 3] frame.  Returns the frame on rank 0, None elsewhere.  `recv` / `frame` may be the buffers of
     gather_buffers() (bench.py reuses them across steps): the slabs land directly in `recv`, and ONE
-    strided copy de-interleaves them — no intermediate copies."""
+    strided copy de-interleaves them — no intermediate copies.  `mark(name)` (optional) is called before the gather
+    ("gather"), after it ("deinterleave") and at the end ("done"): FramePipeline records timing events there."""
     if world == 1 and not force:          # force: run the collective even in a 1-rank group (rehearsal on one GPU)
         return slab
     cols, H, C = slab.shape
     if rank == 0 and recv is None:
         recv, frame = gather_buffers(slab, world, rank, force)
+    if mark: mark("gather")
     dist.gather(slab, list(recv.unbind(0)) if rank == 0 else None, dst=0, group=group)   # the ONE collective of the path
+    if mark: mark("deinterleave")
     if rank != 0:
+        if mark: mark("done")
         return None
     if frame is None:
         frame = torch.empty((cols * world, H, C), dtype=slab.dtype, device=slab.device)
     g = recv.view(world, cols // stripe, stripe, H, C)                                # [rank, stripe j, s, y, c]
     frame.view(cols // stripe, world, stripe, H, C).copy_(g.permute(1, 0, 2, 3, 4))
+    if mark: mark("done")
     return frame
 
 
@@ -74,10 +79,11 @@ class FramePipeline:
     work it enqueues consumes frame k before frame k+1 overwrites the buffer."""
 
     def __init__(self, renders, cols, H, world, rank, stripe, device, streams=None, dtype=torch.float32, group=None,
-                 force=False, on_frame=None):
+                 force=False, on_frame=None, timed=False):
         self.renders = list(renders) if isinstance(renders, (list, tuple)) else [renders]
         self.world, self.rank, self.stripe, self.group, self.force = world, rank, stripe, group, force
         self.on_frame = on_frame
+        self.timed, self._marks = timed, []           # timed: (gather, deinterleave, done) events per frame on the side stream
         self.slabs = [torch.empty((cols, H, 3), dtype=dtype, device=device) for _ in range(2)]
         self.recv, self.frame = gather_buffers(self.slabs[0], world, rank, force)
         self.cuda = self.slabs[0].is_cuda
@@ -109,13 +115,34 @@ class FramePipeline:
             self.rendered[b].record(st)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.rendered[b])
-                out = gather_frame(slab, self.world, self.rank, self.stripe, frame=self.frame, recv=self.recv, group=self.group, force=self.force)
+                mark = None
+                if self.timed:
+                    evs = {}
+                    self._marks.append(evs)
+
+                    def mark(name, evs=evs):
+                        evs[name] = torch.cuda.Event(enable_timing=True)
+                        evs[name].record(self.side)
+                out = gather_frame(slab, self.world, self.rank, self.stripe, frame=self.frame, recv=self.recv, group=self.group, force=self.force, mark=mark)
                 if self.on_frame is not None and self.rank == 0:
                     self.on_frame(self.k, out)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self.gathered[b] = ev
         self.k += 1
+
+    def timings(self, reset=True):
+        """(gather ms, de-interleave ms) summed over the frames submitted since the last call; call after drain() + synchronize.
+        The gather time of a rank includes waiting for the slowest rank's render of that frame."""
+        g = d = 0.0
+        for evs in self._marks:
+            if "gather" in evs and "deinterleave" in evs:
+                g += evs["gather"].elapsed_time(evs["deinterleave"])
+            if "deinterleave" in evs and "done" in evs:
+                d += evs["deinterleave"].elapsed_time(evs["done"])
+        if reset:
+            self._marks = []
+        return g, d
 
     def drain(self):
         """make the current stream wait for every render and gather submitted so far"""

@@ -144,9 +144,15 @@ int ft_camera_look_at(const float position[3], const float look_at[3], const flo
 
 /* ---- the hot path --------------------------------------------------------------------- */
 /* Image.render epsilon length imageSize camera (SdfScene.trace scene)  — Image.fs:26-35 +
- * SdfScene.fs:7-28.  Synchronous.  `out` is host memory (pinned or pageable). */
+ * SdfScene.fs:7-28.  Synchronous.  `out` is host memory (pinned or pageable; a pageable buffer is page-locked for the
+ * duration of the call while the GPU renders, and the frame is copied chunk by chunk behind the rendering). */
 int ft_render(ft_ctx*, const ft_scene*, const ft_camera*, const ft_render_params*,
               float* out, ft_stats* stats);
+/* Page-lock a host buffer the caller reuses as ft_render's `out` (the F# side pins its FColor[,] with GCHandle, as
+ * Image.fs:77-86 does for the bitmap): the frame is then written by DMA at link rate without the per-call pinning
+ * ft_render otherwise does itself.  Unregister before freeing the buffer. */
+int ft_host_register(ft_ctx*, void* p, uint64_t bytes);
+int ft_host_unregister(ft_ctx*, void* p);
 /* Same, output left in device memory `d_out`, launched on the context's stream and NOT
  * synchronised: for callers that keep the frame in HBM (multi-GPU gather, bench). */
 int ft_render_device(ft_ctx*, const ft_scene*, const ft_camera*, const ft_render_params*,

@@ -250,6 +250,45 @@ def test_column_tiles_concatenate_to_full_frame(gpu):
     assert_bit_equal(out, full, "striped tiles")
 
 
+def test_host_output_pipeline_is_bit_identical(gpu, oracle):
+    """ft_render delivers the frame in host memory (Image.render returns a host FColor[,], Image.fs:26-35): large frames are
+    rendered in column chunks on two streams while finished chunks are copied into the page-locked destination.  Registered,
+    unregistered (pinned inside the call) and small (single-launch) frames all equal the frame left in HBM, bit for bit."""
+    import torch
+    scene, _ = syn.config2(seed=6, size=1536)
+    cam = syn.default_camera()
+    ds = gpu.scene(scene)
+    for (W, H) in [(1536, 1024), (2048, 2048), (300, 5000), (64, 64)]:
+        S = ft.ImageSize(W, H)
+        buf = torch.empty((W, H, 3), dtype=torch.float32, device="cuda")
+        ds.render_device(EPS, LEN, S, cam, buf.data_ptr())
+        st0 = ds.collect_stats()
+        want = buf.cpu().numpy()
+        got, st = ds.render(EPS, LEN, S, cam)                      # fresh pageable array: pinned inside the call
+        assert_bit_equal(got, want, f"{W}x{H} pageable")
+        for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "sdf_evals"):
+            assert st[k] == st0[k], k
+        out = np.zeros((W, H, 3), np.float32)
+        gpu.host_register(out)
+        try:
+            got2, _ = ds.render(EPS, LEN, S, cam, out=out)
+            assert got2 is out
+            assert_bit_equal(out, want, f"{W}x{H} registered")
+            part, _ = ds.render(EPS, LEN, S, cam, out=out[:W // 2] if W >= 128 else None, x0=0, n_columns=W // 2) if W >= 128 else (None, None)
+            if part is not None:
+                assert_bit_equal(part, want[:W // 2], "a column range into the front of the registered buffer")
+        finally:
+            gpu.host_unregister(out)
+    with pytest.raises(ft.FrayTracerError):
+        gpu.host_unregister(out)                                   # not registered any more
+    with pytest.raises(ValueError):
+        ds.render(EPS, LEN, ft.ImageSize(64, 64), cam, out=np.zeros((64, 64, 4), np.float32))
+    # against the oracle, through the chunked path
+    full, _ = ds.render(EPS, LEN, ft.ImageSize(1536, 1536), cam)
+    o, _ = oracle.Oracle().scene(scene).render(EPS, LEN, 1536, 1536, cam.as_array(), xstep=64)
+    assert_bit_equal(full[::64], o, "chunked host output against the oracle")
+
+
 def test_render_multi_single_process_path(gpu):
     """ft_render_multi with the one GPU this box has: stripes + (degenerate) gather + de-interleaving copy
     must reproduce the monolithic render; two contexts on the same device exercise ft_scene_clone and the

@@ -4,17 +4,10 @@
 # Writes gpurun_out/prof_<tag>/{trace,pmc_sq,pmc_sq2,pmc_fetch,pmc_write}; copy the summaries to profiles/.
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 3 --warmup 1 --no-cpu-baseline --no-spp4}
+ARGS=${*:---steps 3 --warmup 1 --no-cpu-baseline --no-side}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-# the lean kernel exists with two loop placements and a context times both on its first frame; learn this box's
-# choice first and force it for the profiled runs, so that the 4 short calibration launches stay out of the counters
-if [ -z "${FT_LEAN_ALT:-}" ]; then
-    CHOICE=$(python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-spp4 2>/dev/null | python3 -c "import sys, json; print(1 if json.loads(sys.stdin.read().strip().splitlines()[-1])['roofline']['kernel'].endswith('_alt') else 0)")
-    export FT_LEAN_ALT=${CHOICE:-0}
-    echo "lean kernel placement on this box: FT_LEAN_ALT=$FT_LEAN_ALT" > "$OUT/lean_choice.txt"
-fi
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1 || echo "trace pass failed"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE \
@@ -25,5 +18,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1 || echo "write pass failed"
 cd "$REPO"
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
-cat "$OUT/lean_choice.txt" >> "$OUT/summary.txt" 2>/dev/null
 cat "$OUT/summary.txt"
