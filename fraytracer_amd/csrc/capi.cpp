@@ -181,8 +181,8 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     return FT_OK;
 }
 
-// per-lane value slots (distance + material index), the staged constant-pool prefix, 7 per-lane statistics words
-size_t ldsBytes(const ft_scene* s) { return (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4 + (size_t)7 * FT_BLOCK * 4; }
+// statistics header, per-lane value slots (distance + material index), the staged constant-pool prefix
+size_t ldsBytes(const ft_scene* s) { return (size_t)FT_LDS_HDR_FLOATS * 4 + (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4; }
 
 // A frame loop that never calls ft_collect_stats must not grow the event list: beyond this many pending pairs the
 // oldest one is folded into foldedMs (it has long completed: launches on one stream finish in order) and recycled.

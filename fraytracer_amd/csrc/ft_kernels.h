@@ -7,6 +7,9 @@
 #include "ft_device.h"
 
 #define FT_BLOCK 256          // 4 waves; every wave is an independent persistent worker
+// dynamic LDS of a trace workgroup starts with FT_LDS_STAT_ROWS rows of per-lane statistics words and 4 clock dwords
+#define FT_LDS_STAT_ROWS 7
+#define FT_LDS_HDR_FLOATS (FT_LDS_STAT_ROWS * FT_BLOCK + 4)
 
 struct FtRenderArgs {
     FtSceneDev S;

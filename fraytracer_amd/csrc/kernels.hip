@@ -61,6 +61,8 @@ __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float ft_lds[];
 enum : uint32_t { FT_C_EVALS = 0, FT_C_SHADOW, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
+static_assert(FT_C_COUNT == FT_LDS_STAT_ROWS, "ft_kernels.h: FT_LDS_STAT_ROWS");
+// behind the statistics rows: 4 dwords holding the start clocks of the workgroup's first wave (FT_LDS_HDR_FLOATS in total)
 __device__ __forceinline__ void ft_count(uint32_t k) {
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + k * FT_BLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -738,12 +740,12 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 template <int VARIANT, bool EXT>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const bool clockWave = blockIdx.x == 0 && tid < 64u;              // this wave reports the shader clock it ran at (statistics only)
-    unsigned long long clkS = 0, clkR = 0;
-    if (clockWave) { clkS = clock64(); clkR = wall_clock64(); }
-    float* sd = ft_lds + FT_C_COUNT * FT_BLOCK + tid;
-    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + (FT_C_COUNT + a.S.nSlots) * FT_BLOCK) + tid;
-    float* ldsC = ft_lds + (FT_C_COUNT + 2u * a.S.nSlots) * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
+    // the first wave of block 0 reports the shader clock it ran at (statistics only); its start clocks wait in LDS, not in registers
+    unsigned long long* clk0 = reinterpret_cast<unsigned long long*>(ft_lds + FT_C_COUNT * FT_BLOCK);
+    if (blockIdx.x == 0 && tid == 0) { clk0[0] = clock64(); clk0[1] = wall_clock64(); }
+    float* sd = ft_lds + FT_LDS_HDR_FLOATS + tid;
+    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + FT_LDS_HDR_FLOATS + a.S.nSlots * FT_BLOCK) + tid;
+    float* ldsC = ft_lds + FT_LDS_HDR_FLOATS + 2u * a.S.nSlots * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
     for (uint32_t i = tid; i < a.S.nStage; i += FT_BLOCK) ldsC[i] = a.S.consts[i];
     for (uint32_t k = 0; k < FT_C_COUNT; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
     __syncthreads();
@@ -871,7 +873,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         if (ex) atomicAdd(&a.stats->rays_ext, ex);
         atomicAdd(&a.stats->wave_evals, (unsigned long long)waveEvals);
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
-        if (clockWave) { atomicAdd(&a.stats->clk_shader, clock64() - clkS); atomicAdd(&a.stats->clk_ref, wall_clock64() - clkR); }
+        if (blockIdx.x == 0 && tid == 0) { atomicAdd(&a.stats->clk_shader, clock64() - clk0[0]); atomicAdd(&a.stats->clk_ref, wall_clock64() - clk0[1]); }
     }
 }
 
@@ -890,9 +892,9 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
                                                                             long long n, float* __restrict__ outD, int* __restrict__ outM) {
     const uint32_t tid = threadIdx.x;
-    float* sd = ft_lds + FT_C_COUNT * FT_BLOCK + tid;              // same LDS layout as the trace kernel (flag words first, unused here)
-    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + (FT_C_COUNT + S.nSlots) * FT_BLOCK) + tid;
-    float* ldsC = ft_lds + (FT_C_COUNT + 2u * S.nSlots) * FT_BLOCK;
+    float* sd = ft_lds + FT_LDS_HDR_FLOATS + tid;                  // same LDS layout as the trace kernel (flag words first, unused here)
+    uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + FT_LDS_HDR_FLOATS + S.nSlots * FT_BLOCK) + tid;
+    float* ldsC = ft_lds + FT_LDS_HDR_FLOATS + 2u * S.nSlots * FT_BLOCK;
     for (uint32_t i = tid; i < S.nStage; i += FT_BLOCK) ldsC[i] = S.consts[i];
     __syncthreads();
     for (long long i = (long long)blockIdx.x * FT_BLOCK + tid; i < n; i += (long long)gridDim.x * FT_BLOCK) {

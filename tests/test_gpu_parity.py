@@ -254,16 +254,17 @@ def test_host_output_pipeline_is_bit_identical(gpu, oracle):
     """ft_render delivers the frame in host memory (Image.render returns a host FColor[,], Image.fs:26-35): large frames are
     rendered in column chunks on two streams while finished chunks are copied into the page-locked destination.  Registered,
     unregistered (pinned inside the call) and small (single-launch) frames all equal the frame left in HBM, bit for bit."""
-    import torch
+    import os
     scene, _ = syn.config2(seed=6, size=1536)
     cam = syn.default_camera()
     ds = gpu.scene(scene)
     for (W, H) in [(1536, 1024), (2048, 2048), (300, 5000), (64, 64)]:
         S = ft.ImageSize(W, H)
-        buf = torch.empty((W, H, 3), dtype=torch.float32, device="cuda")
-        ds.render_device(EPS, LEN, S, cam, buf.data_ptr())
-        st0 = ds.collect_stats()
-        want = buf.cpu().numpy()
+        os.environ["FT_HOST_CHUNKS"] = "1"; os.environ["FT_HOST_NO_PIN"] = "1"      # one launch, one pageable copy after it
+        try:
+            want, st0 = ds.render(EPS, LEN, S, cam)
+        finally:
+            del os.environ["FT_HOST_CHUNKS"], os.environ["FT_HOST_NO_PIN"]
         got, st = ds.render(EPS, LEN, S, cam)                      # fresh pageable array: pinned inside the call
         assert_bit_equal(got, want, f"{W}x{H} pageable")
         for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "sdf_evals"):

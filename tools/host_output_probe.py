@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np
     import fraytracer_amd as ft
     from fraytracer_amd import synthetic as syn
-    tag, registered = sys.argv[2], sys.argv[3] == "1"
+    tag, registered, cold = sys.argv[2], sys.argv[3] == "1", sys.argv[3] == "cold"
     size = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
     scene, _ = syn.config3(size=size)
     cam = syn.default_camera()
@@ -23,7 +23,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ref, _ = ds.render(syn.EPSILON, syn.RAY_LENGTH, S, cam)
     ds.render(syn.EPSILON, syn.RAY_LENGTH, S, cam, out=out)
     ts, kms = [], []
+    keep = []
     for _ in range(6):
+        if cold:                                            # a fresh, untouched destination per frame (what a new FColor[,] is)
+            keep.append(out)
+            out = np.empty((size, size, 3), np.float32)
         t0 = time.perf_counter()
         _, st = ds.render(syn.EPSILON, syn.RAY_LENGTH, S, cam, out=out)
         ts.append((time.perf_counter() - t0) * 1e3); kms.append(st["kernel_ms"])
@@ -41,6 +45,9 @@ for tag, env, reg in (("old path: pageable, one copy after the kernel", {"FT_HOS
                       ("pageable destination, pinned inside the call, 1 chunk", {"FT_HOST_CHUNKS": "1"}, "0"),
                       ("pageable destination, pinned inside the call, 2 chunks", {"FT_HOST_CHUNKS": "2"}, "0"),
                       ("pageable destination, pinned inside the call, 8 chunks", {"FT_HOST_CHUNKS": "8"}, "0"),
+                      ("fresh untouched destination per frame, old path", {"FT_HOST_NO_PIN": "1", "FT_HOST_CHUNKS": "1"}, "cold"),
+                      ("fresh untouched destination per frame, pinned inside the call, 4 chunks", {}, "cold"),
+                      ("fresh untouched destination per frame, not pinned, 4 chunks", {"FT_HOST_NO_PIN": "1"}, "cold"),
                       ("destination registered once (ft_host_register), 4 chunks", {}, "1"),
                       ("destination registered once, 8 chunks", {"FT_HOST_CHUNKS": "8"}, "1"),
                       ("destination registered once, 1 chunk", {"FT_HOST_CHUNKS": "1"}, "1")):
