@@ -223,6 +223,13 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     // one 8x8 tile per grab: measured faster than larger chunks (lanes of a wave stay on neighbouring
     // pixels) and 2.6e5 atomics per 4096^2 frame are far below the rate one counter sustains
     a.chunk = 64;
+    // burst refill (kernels.hip): a wave takes new rays only when all 64 lanes are idle, i.e. it works through one 8x8 tile at a
+    // time.  Measured (profiles/r02_refill_sweep.txt, kernel ms at refillMin = 1 / 32 / 64): 1000-torus scene 4000^2 22.5 /
+    // 15.8 / 12.1, at 1000^2 2.98 / 2.72 / 2.24, C2 4096^2 4.90 / 4.40 / 3.84, 300 on-demand combinators 24.6 / 14.8 / 10.3,
+    // glass config 39.1 / 31.5 / 27.3, and even the VALU-bound C3 kernel 61.0 / 66.5 / 60.3: rays that start together stay in
+    // step (march, the four normal probes, shadow rays), so a wave's lanes share lookup cells, list positions and branches.
+    a.refillMin = 64u;
+    if (const char* e = getenv("FT_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.refillMin = (uint32_t)v; }   // experiments
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;

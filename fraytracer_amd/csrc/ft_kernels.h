@@ -8,7 +8,11 @@
 
 #define FT_BLOCK 256          // 4 waves; every wave is an independent persistent worker
 // dynamic LDS of a trace workgroup starts with FT_LDS_STAT_ROWS rows of per-lane statistics words and 4 clock dwords
+#ifdef FT_UNION_PROFILE
+#define FT_LDS_STAT_ROWS 15   // diagnostic build: + 8 rows of union-walk counters (kernels.hip FT_UDBG)
+#else
 #define FT_LDS_STAT_ROWS 7
+#endif
 #define FT_LDS_HDR_FLOATS (FT_LDS_STAT_ROWS * FT_BLOCK + 4)
 
 struct FtRenderArgs {
@@ -29,7 +33,7 @@ struct FtRenderArgs {
     uint32_t ext;             // 1: launch the EXTENSION build of the kernel (set by the host, see capi.cpp)
     uint32_t maxBounces;      // EXTENSION glass: interactions per path; 0 = glass shades as a solid
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
-    uint32_t pad2;
+    uint32_t refillMin;       // idle lanes a wave waits for before it takes new rays (1 = refill at once; kernels.hip "Burst refill")
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move
     float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)
@@ -59,6 +63,8 @@ hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long
 // Image.toColors (+ toBitmap order) on the device: max pass + map pass on one stream; maxBits = 4 bytes of device scratch
 hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_t* maxBits, float gammaInv, uint32_t dither, uint32_t seed,
                              int bmpOrder, unsigned char* out, unsigned numCUs, hipStream_t st);
+// ft_render_multi: gathered slabs [rank][stripe][...] -> frame [stripe][rank][...] on the device
+hipError_t ft_launch_deinterleave(const float* recv, float* frame, unsigned long long stripeFloats, uint32_t nStripes, uint32_t nRanks, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
 hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus

@@ -61,7 +61,7 @@ __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float ft_lds[];
 enum : uint32_t { FT_C_EVALS = 0, FT_C_SHADOW, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
-static_assert(FT_C_COUNT == FT_LDS_STAT_ROWS, "ft_kernels.h: FT_LDS_STAT_ROWS");
+static_assert(FT_C_COUNT <= FT_LDS_STAT_ROWS, "ft_kernels.h: FT_LDS_STAT_ROWS");
 // behind the statistics rows: 4 dwords holding the start clocks of the workgroup's first wave (FT_LDS_HDR_FLOATS in total)
 __device__ __forceinline__ void ft_count(uint32_t k) {
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + k * FT_BLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -262,20 +262,33 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 // Per-lane candidate list; lanes of a wave are neighbouring pixels and mostly share the cell.
 // ------------------------------------------------------------------------------------------------
 #ifdef FT_UNION_PROFILE
-// diagnostic build only (`make profile`, tools/union_divergence.py): [0] loop trips summed over lanes, [1] loop trips per wave x 64,
-// [2] candidate evaluations summed over lanes, [3] candidate-evaluation blocks per wave x 64
-__device__ unsigned long long ft_union_dbg[4];
-#define FT_UDBG(k, v) atomicAdd(&ft_union_dbg[k], (unsigned long long)(v))
-#define FT_UDBG_WAVE(k) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&ft_union_dbg[k], 64ull); } while (0)
+// diagnostic build only (`make profile`, tools/union_divergence.py).  Counters are per-lane words in LDS (rows behind the
+// statistics rows, one ds_add per event) and are summed into ft_union_dbg when the kernel ends, so that counting does not slow
+// the loop it measures: [0] loop trips summed over lanes, [1] loop trips per wave x 64, [2] candidate evaluations summed over
+// lanes, [3] candidate-evaluation blocks per wave x 64, [4] shader cycles inside the union walk (per wave), [5] inside the whole
+// scene evaluation, [6] wave-level evaluations x 64, [7] shader cycles of whole rounds (evaluation + state machine + refill)
+__device__ unsigned long long ft_union_dbg[8];
+__device__ __forceinline__ void ft_dbg_add(uint32_t k, uint32_t v) {
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + (7u + k) * FT_BLOCK, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool ft_dbg_leader() { return (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1); }
+__device__ __forceinline__ uint32_t ft_dbg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return (uint32_t)t; }
+#define FT_UDBG(k, v) ft_dbg_add(k, v)
+#define FT_UDBG_WAVE(k) do { if (ft_dbg_leader()) ft_dbg_add(k, 64u); } while (0)
+#define FT_UDBG_T0(v) const uint32_t v = ft_dbg_now()
+#define FT_UDBG_T1(k, v) do { const uint32_t _t = ft_dbg_now(); if (ft_dbg_leader()) ft_dbg_add(k, _t - (v)); } while (0)
 #else
 #define FT_UDBG(k, v) do {} while (0)
 #define FT_UDBG_WAVE(k) do {} while (0)
+#define FT_UDBG_T0(v) do {} while (0)
+#define FT_UDBG_T1(k, v) do {} while (0)
 #endif
 
 template <bool FQ>
 __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            const float* __restrict__ sd, const uint32_t* __restrict__ sl,
                                            float& outD, uint32_t& outLeaf) {   // unions without FT_PR_CALL children
+    FT_UDBG_T0(tWalk);
     const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
     const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
     const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
@@ -289,31 +302,47 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     uint32_t i = cellStart[cell];
     const uint32_t end = cellStart[cell + 1];
 
-    float mn; uint32_t leaf;
-    {                                                                  // Items.[0]  (SdfForm.fs:26)
-        const ItemRegs rec = ld_item(items + i);
-        const uint32_t type = rec.b.y & 15u, data = rec.b.y >> 4;
-        if (type == FT_PR_SLOT) { mn = sd[data * FT_BLOCK]; leaf = sl[data * FT_BLOCK]; }
-        else { mn = prim_eval_t<FQ>(type, consts + data, p); leaf = rec.b.z; }
-    }
-    // The reference scans the whole list (SdfForm.fs:27).  The list is sorted by LowerBound
-    // (SdfBoundary.fs:267-268; verified NaN-free when the grid is built) and `mn` never grows, so once
-    // `mn > LowerBound - distanceToCenter` (:30) fails for one candidate it fails for every later one
-    // (float subtraction is monotonic): leaving the loop there gives the identical result.
-    for (++i; i < end; ++i) {
-        const ItemRegs cur = ld_item(items + i);
+    // The reference scans the whole list (SdfForm.fs:27), testing  min > LowerBound - distanceToCenter (:30)  and
+    // min > getMinDistance (:31)  before it evaluates a candidate.  The list is sorted by LowerBound (SdfBoundary.fs:267-268;
+    // verified NaN-free when the grid is built) and `mn` never grows, so once :30 fails for one candidate it fails for every
+    // later one (float subtraction is monotonic): leaving the loop there gives the identical result.
+    //
+    // The walk is bound by the latency of its dependent steps (it speeds up in proportion to the resident waves), so every
+    // trip handles TWO candidates: both 32-byte records are requested together (they share a 64-byte line half of the time)
+    // and both candidates' right-hand sides of :30 / :31 — which do not depend on `mn` — are computed side by side; the
+    // decisions are then taken in list order.  An evaluation (8 % of the candidates) is done in one place for either of the
+    // two, after which the walk resumes behind the evaluated candidate.  Items.[0] is evaluated unconditionally (:26): it
+    // enters that same place with both tests forced true.
+    float mn = 0.0f; uint32_t leaf = 0;
+    bool first = true;
+    while (i < end) {
+        const uint32_t j = i + 1u < end ? i + 1u : i;
+        const ItemRegs ra = ld_item(items + i), rb = ld_item(items + j);
         FT_UDBG(0, 1); FT_UDBG_WAVE(1);
-        if (!(mn > cur.a.x - distanceToCenter)) break;                 // :30 false for this and all later candidates
-        if (mn > ft_dist<FQ>(mk3(cur.a.y, cur.a.z, cur.a.w), p) - __uint_as_float(cur.b.x)) {   // :31 getMinDistance
-            FT_UDBG(2, 1); FT_UDBG_WAVE(3);
-            const uint32_t type = cur.b.y & 15u, data = cur.b.y >> 4;
-            float d; uint32_t l;
-            if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
-            else { d = prim_eval_t<FQ>(type, consts + data, p); l = cur.b.z; }
+        const float lbA = ra.a.x - distanceToCenter, lbB = rb.a.x - distanceToCenter;
+        const float mdA = ft_dist<FQ>(mk3(ra.a.y, ra.a.z, ra.a.w), p) - __uint_as_float(ra.b.x);    // :31 getMinDistance
+        const float mdB = ft_dist<FQ>(mk3(rb.a.y, rb.a.z, rb.a.w), p) - __uint_as_float(rb.b.x);
+        uint32_t typeData, mat;
+        if (first || (mn > lbA && mn > mdA)) { typeData = ra.b.y; mat = ra.b.z; i += 1u; }          // evaluate A, resume at B
+        else {
+            if (!(mn > lbA)) break;                                    // :30 false for A and every later candidate
+            if (j == i || !(mn > lbB)) break;                          // list ends with A, or :30 false for B
+            i += 2u;
+            if (!(mn > mdB)) continue;                                 // neither candidate is evaluated
+            typeData = rb.b.y; mat = rb.b.z;                           // evaluate B
+        }
+        FT_UDBG(2, 1); FT_UDBG_WAVE(3);
+        const uint32_t type = typeData & 15u, data = typeData >> 4;
+        float d; uint32_t l;
+        if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
+        else { d = prim_eval_t<FQ>(type, consts + data, p); l = mat; }
+        if (first) { mn = d; leaf = l; first = false; }
+        else {
             if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
             mn = ft_min(mn, d);                                        // SdfForm.fs:33
         }
     }
+    FT_UDBG_T1(4, tWalk);
     outD = mn; outLeaf = leaf;
 }
 
@@ -741,13 +770,13 @@ template <int VARIANT, bool EXT>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the first wave of block 0 reports the shader clock it ran at (statistics only); its start clocks wait in LDS, not in registers
-    unsigned long long* clk0 = reinterpret_cast<unsigned long long*>(ft_lds + FT_C_COUNT * FT_BLOCK);
+    unsigned long long* clk0 = reinterpret_cast<unsigned long long*>(ft_lds + FT_LDS_STAT_ROWS * FT_BLOCK);
     if (blockIdx.x == 0 && tid == 0) { clk0[0] = clock64(); clk0[1] = wall_clock64(); }
     float* sd = ft_lds + FT_LDS_HDR_FLOATS + tid;
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + FT_LDS_HDR_FLOATS + a.S.nSlots * FT_BLOCK) + tid;
     float* ldsC = ft_lds + FT_LDS_HDR_FLOATS + 2u * a.S.nSlots * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
     for (uint32_t i = tid; i < a.S.nStage; i += FT_BLOCK) ldsC[i] = a.S.consts[i];
-    for (uint32_t k = 0; k < FT_C_COUNT; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
+    for (uint32_t k = 0; k < FT_LDS_STAT_ROWS; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
     __syncthreads();
 
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
@@ -765,6 +794,11 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         for (int round = 0; round < 3; ++round) {
             const unsigned long long idle = __ballot(s.phase == PH_IDLE);
             if (idle == 0ull) break;
+            // Burst refill: new rays are taken only when at least refillMin lanes are idle (or nothing is left to evaluate).  Rays
+            // that start together on one 8x8 tile stay close in depth, so the lanes of a wave keep visiting the same lookup
+            // cells and list positions: their record loads coalesce and their walks have similar lengths.  That is worth far
+            // more to the grid-union kernels than the idle lanes cost (capi.cpp launchTrace picks refillMin per kernel).
+            if ((uint32_t)__popcll(idle) < a.refillMin && __ballot(s.phase >= PH_MARCH) != 0ull) break;
             if (chunkNext == chunkEnd) {
                 if (exhausted) break;
                 uint32_t base = 0;
@@ -786,6 +820,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         // ---- one scene-SDF evaluation per active lane -----------------------------------------
         const bool active = s.phase >= PH_MARCH;
         waveEvals += 1;
+        FT_UDBG_T0(tRound);
         if (active) {
             f3 q = s.o;
             if (s.phase >= PH_NX && s.phase <= PH_NC) {                // SdfForm.fs:106-115
@@ -797,8 +832,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 if (s.phase == PH_NZ) q.z = base.z + h;
             }
             float d; uint32_t leaf;
+            FT_UDBG_T0(tEval);
             if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
             else ft_eval<VARIANT == 2>(a.S, q, sd, sl, ldsC, d, leaf);
+            FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
             ft_count(FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
 
@@ -854,6 +891,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             }
             settle<EXT>(a, s);
         }
+        FT_UDBG_T1(7, tRound);
     }
 
     // ---- statistics -------------------------------------------------------------------------
@@ -875,17 +913,40 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
         if (blockIdx.x == 0 && tid == 0) { atomicAdd(&a.stats->clk_shader, clock64() - clk0[0]); atomicAdd(&a.stats->clk_ref, wall_clock64() - clk0[1]); }
     }
+#ifdef FT_UNION_PROFILE
+    for (uint32_t k = 0; k < 8; ++k) {
+        const unsigned long long v = wave_sum(cw[(7u + k) * FT_BLOCK]);
+        if (lane == 0 && v) atomicAdd(&ft_union_dbg[k], v);
+    }
+#endif
 }
 
+// Occupancy hints.  The general kernels are bound by the latency of their dependent steps (grid-union walk: time falls almost in
+// proportion to the resident waves up to 5 per SIMD), so the register allocator is asked for one wave more
+// than it would settle on by itself where that costs (almost) no spills: 6 waves (80 VGPRs) for the plain kernel (1000-torus scene
+// 23.5 -> 22.4 ms; 7 waves spill and are slower), 5 waves (96 VGPRs) for its EXTENSION build (C2 + AO 16.9 -> 14.9 ms) and for the
+// kernel with on-demand sub-programs (24.7 -> 24.1 ms).
+#ifndef FT_GENERAL_WAVES
+#define FT_GENERAL_WAVES 6
+#endif
+#define FT_OCC(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#ifndef FT_CALLS_WAVES
+#define FT_CALLS_WAVES 5
+#endif
+#ifndef FT_EXT_WAVES
+#define FT_EXT_WAVES 5
+#endif
+#define FT_CALLS_OCC FT_OCC(FT_CALLS_WAVES)
+#define FT_EXT_OCC FT_OCC(FT_EXT_WAVES)
 // general scenes
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel(const FtRenderArgs a) { ft_trace_body<0, false>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_OCC(FT_GENERAL_WAVES) ft_trace_kernel(const FtRenderArgs a) { ft_trace_body<0, false>(a); }
 // scenes that are one smooth union of spheres (BASELINE.json config 3/4)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres(const FtRenderArgs a) { ft_trace_body<1, false>(a); }
 // EXTENSION builds of both (spp > 1 and / or ambient occlusion); the reference path never pays for them
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_ext(const FtRenderArgs a) { ft_trace_body<0, true>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_EXT_OCC ft_trace_kernel_ext(const FtRenderArgs a) { ft_trace_body<0, true>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_ext(const FtRenderArgs a) { ft_trace_body<1, true>(a); }
 // general scenes whose unions have combinator children evaluated on demand (FT_PR_CALL, FtSceneDev.fastPath == 2)
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_CALLS_OCC ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
 
 // scene.Object.Form.Distance at explicit points (test / diagnostic entry)
@@ -1077,6 +1138,25 @@ extern "C" __global__ void ft_grid_compact_kernel(const FtItem* __restrict__ tmp
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) items[beg + i] = tmp[(size_t)cell * n + i];
 }
 
+// multi-GPU: gathered slabs [rank][stripe j][S columns] -> frame [stripe j][rank][S columns] (ft_render_multi; the Python path
+// does the same with one strided torch copy).  One stripe = stripeVec float4 (or float) elements, contiguous on both sides.
+template <class T>
+__global__ void ft_deinterleave_kernel(const T* __restrict__ recv, T* __restrict__ frame, unsigned long long stripeVec, uint32_t nStripes, uint32_t nRanks) {
+    const unsigned long long total = stripeVec * nStripes * nRanks;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long t = i % stripeVec, sj = i / stripeVec;          // sj = j * nRanks + r in the frame
+        const unsigned long long j = sj / nRanks, r = sj % nRanks;
+        frame[i] = recv[(r * nStripes + j) * stripeVec + t];
+    }
+}
+extern "C" hipError_t ft_launch_deinterleave(const float* recv, float* frame, unsigned long long stripeFloats, uint32_t nStripes, uint32_t nRanks, hipStream_t st) {
+    if (stripeFloats % 4ull == 0ull && ((uintptr_t)recv & 15u) == 0 && ((uintptr_t)frame & 15u) == 0)
+        hipLaunchKernelGGL(ft_deinterleave_kernel<float4>, dim3(4096), dim3(256), 0, st, reinterpret_cast<const float4*>(recv), reinterpret_cast<float4*>(frame),
+                           stripeFloats / 4ull, nStripes, nRanks);
+    else
+        hipLaunchKernelGGL(ft_deinterleave_kernel<float>, dim3(4096), dim3(256), 0, st, recv, frame, stripeFloats, nStripes, nRanks);
+    return hipGetLastError();
+}
 // exhaustive proof of the fast forms: every float bit pattern in [lo, hi] (same sign), fast vs exact
 extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, unsigned long long* mismatches) {
     unsigned long long bad = 0;
@@ -1170,10 +1250,10 @@ extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsig
     return hipGetLastError();
 }
 #ifdef FT_UNION_PROFILE
-extern "C" hipError_t ft_debug_union_counters(unsigned long long out[4]) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 4);
+extern "C" hipError_t ft_debug_union_counters(unsigned long long out[8]) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 8);
     if (e != hipSuccess) return e;
-    unsigned long long zero[4] = {0, 0, 0, 0};
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(ft_union_dbg), zero, sizeof(zero));
 }
 #endif

@@ -5,7 +5,15 @@
 // collection of the finished slabs.  Columns are dealt in stripes of `stripe_width` so that the
 // expensive centre of the image is spread over all devices; because the output is column-major
 // (Array2D.fs:30-38) every stripe is one contiguous run of stripe_width*height*3 floats in both
-// the gathered buffer and the final image, so de-interleaving is part of the device->host copy.
+// the gathered buffer and the final image: one strided device copy (ft_deinterleave_kernel) puts the gathered slabs
+// in frame order on the first device and ONE device->host copy delivers the frame.
+//
+// Threading and RCCL: the communicators come from ncclCommInitAll (one per device, cached), and every device has its own
+// host thread, which renders on its context's stream and then calls ncclGather on ITS communicator and stream.  That is
+// RCCL's "one thread per device" mode, in which the per-rank calls of one collective are issued concurrently by
+// construction; ncclGroupStart / ncclGroupEnd are for the other mode — one thread issuing the calls of several
+// communicators in a loop, where the first call would otherwise block waiting for its peers — and are not used here.
+// Slabs, the gather buffer and the frame buffer are cached between calls (same devices, same size).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library itself is loaded on first use
@@ -16,6 +24,7 @@
 #include <vector>
 
 #include "../../include/fraytracer_hip.h"
+#include "ft_kernels.h"
 
 // small internal hooks exported by capi.cpp
 extern "C" {
@@ -32,6 +41,36 @@ struct CommCache {
 };
 std::mutex g_mu;
 CommCache g_cache;
+
+// device buffers of ft_render_multi, kept between calls: one slab per device, and on the first device the gather
+// buffer [n x slab] and the de-interleaved frame [n x slab]
+struct BufCache {
+    std::vector<int> devices;
+    size_t slabFloats = 0;
+    std::vector<float*> send;
+    float* recv = nullptr;
+    float* frame = nullptr;
+    void release() {
+        for (size_t r = 0; r < send.size(); ++r) if (send[r]) { (void)hipSetDevice(devices[r]); (void)hipFree(send[r]); }
+        if (!devices.empty()) (void)hipSetDevice(devices[0]);
+        if (recv) (void)hipFree(recv);
+        if (frame) (void)hipFree(frame);
+        *this = BufCache{};
+    }
+    bool ensure(const std::vector<int>& devs, size_t slab) {
+        if (devices == devs && slabFloats == slab) return true;
+        release();
+        devices = devs; slabFloats = slab; send.assign(devs.size(), nullptr);
+        for (size_t r = 0; r < devs.size(); ++r)
+            if (hipSetDevice(devs[r]) != hipSuccess || hipMalloc((void**)&send[r], slab * sizeof(float)) != hipSuccess) { release(); return false; }
+        if (devs.size() > 1) {
+            if (hipSetDevice(devs[0]) != hipSuccess || hipMalloc((void**)&recv, slab * devs.size() * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&frame, slab * devs.size() * sizeof(float)) != hipSuccess) { release(); return false; }
+        }
+        return true;
+    }
+};
+BufCache g_bufs;
 
 int fail(int code, const std::string& m) { ft_set_error_(code, m.c_str()); return code; }
 
@@ -101,26 +140,12 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
     for (int r = 1; r < n; ++r) sameDevice = sameDevice && devs[r] == devs[0];
     if (n > 1 && !sameDevice && !getComms(devs, comms, err)) return fail(FT_ERR_COMM, err);
 
-    std::vector<float*> send(n, nullptr);
-    float* recv = nullptr;
+    if (!g_bufs.ensure(devs, slab)) return fail(FT_ERR_HIP, "hipMalloc of the stripe slabs / gather buffers failed");
+    const std::vector<float*>& send = g_bufs.send;
+    float* recv = g_bufs.recv;
     std::vector<int> rcs(n, FT_OK);
     std::vector<std::string> errs(n);
     std::vector<ft_stats> sts(n);
-
-    auto cleanup = [&]() {
-        for (int r = 0; r < n; ++r) if (send[r]) { (void)hipSetDevice(devs[r]); (void)hipFree(send[r]); }
-        if (recv) { (void)hipSetDevice(devs[0]); (void)hipFree(recv); }
-    };
-    for (int r = 0; r < n; ++r) {
-        if (hipSetDevice(devs[r]) != hipSuccess || hipMalloc((void**)&send[r], slab * sizeof(float)) != hipSuccess) {
-            cleanup(); return fail(FT_ERR_HIP, "hipMalloc of a stripe slab failed");
-        }
-    }
-    if (n > 1) {
-        if (hipSetDevice(devs[0]) != hipSuccess || hipMalloc((void**)&recv, slab * n * sizeof(float)) != hipSuccess) {
-            cleanup(); return fail(FT_ERR_HIP, "hipMalloc of the gather buffer failed");
-        }
-    }
 
     auto worker = [&](int r) {
         ft_render_params p = *full;
@@ -142,19 +167,21 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
         for (int r = 0; r < n; ++r) ts.emplace_back(worker, r);
         for (auto& t : ts) t.join();
     }
-    for (int r = 0; r < n; ++r) if (rcs[r] != FT_OK) { cleanup(); return fail(rcs[r], errs[r]); }
+    for (int r = 0; r < n; ++r) if (rcs[r] != FT_OK) return fail(rcs[r], errs[r]);
 
-    // de-interleave while copying out: stripe j of device r is columns [(j*n + r)*S, +S)
+    // stripe j of device r is columns [(j*n + r)*S, +S) of the frame: one strided copy on the first device, one copy out
+    // (every worker has synchronised its stream in ft_collect_stats, so the gathered data is complete)
     (void)hipSetDevice(devs[0]);
-    const float* src = n > 1 ? recv : send[0];
-    const size_t stripeFloats = (size_t)S * H * 3;
+    const float* src = send[0];
     hipError_t he = hipSuccess;
-    for (int r = 0; r < n && he == hipSuccess; ++r)
-        for (int j = 0; j < cols / S && he == hipSuccess; ++j)
-            he = hipMemcpy(out + ((size_t)(j * n + r) * S) * H * 3, src + (size_t)r * slab + (size_t)j * stripeFloats,
-                           stripeFloats * sizeof(float), hipMemcpyDeviceToHost);
-    cleanup();
-    if (he != hipSuccess) return fail(FT_ERR_HIP, std::string("hipMemcpy of the gathered image: ") + hipGetErrorString(he));
+    if (n > 1) {
+        hipStream_t st0 = (hipStream_t)ft_ctx_stream_(ctxs[0]);
+        he = ft_launch_deinterleave(recv, g_bufs.frame, (unsigned long long)S * H * 3, (uint32_t)(cols / S), (uint32_t)n, st0);
+        if (he == hipSuccess) he = hipStreamSynchronize(st0);
+        src = g_bufs.frame;
+    }
+    if (he == hipSuccess) he = hipMemcpy(out, src, slab * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) return fail(FT_ERR_HIP, std::string("de-interleave / copy of the gathered image: ") + hipGetErrorString(he));
 
     if (stats) {
         *stats = ft_stats{};
