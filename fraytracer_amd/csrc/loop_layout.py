@@ -3,12 +3,14 @@
 
 Measured on gfx950 (tools/asm_variants*.py, tools/pad_sweep.py; profiles/r02_*): the 4-children-per-trip loops of
 smooth_run_spheres_fast consist of ~72 four-byte instructions (distances, square roots) followed by ONE run of ~38
-64-bit encoded VALU instructions (the exp part).  When that run starts on an 8-byte boundary a C3 frame takes 0.1477 G
-shader cycles, when it starts at 4 mod 8 it takes 0.1377 G (-7 %) — the same on every MI355X tried; which of the two a
-plain compile produces is a lottery of the preceding code (a one-dword change flips it).  This pass removes the lottery:
+64-bit encoded VALU instructions (the exp part).  When that run starts on an 8-byte boundary a C3 frame takes 0.148-0.155 G
+shader cycles, when it starts at 4 mod 8 it takes 0.1377-0.1395 G (-7 ... -10 %) — the same on every MI355X tried; which of
+the two a plain compile produces is a lottery of the preceding code (a one-dword change flips it).  A scan of all single-s_nop
+insertions (profiles/r02_asm_nopscan2.jsonl) shows the best layout: loop head at 4 mod 8 AND the run at 4 mod 8 (another 1 %),
+which takes one s_nop inside the loop, anywhere in the 40 instructions before the run.  This pass removes the lottery:
 every loop is preceded (kernels.hip FT_LOOP_PHASE) by `.p2align 6` + `.rept N` s_nops; the pass assembles the device
-assembly, disassembles it, finds every such loop and sets N to 0 or 1 so that the loop's longest run of 64-bit VALU
-instructions starts at 4 mod 8, and verifies the result.
+assembly, disassembles it, finds every such loop, sets N to 0 or 1 so that the loop head lands at 4 mod 8, inserts one
+`s_nop 0` fourteen instructions ahead of the run where the run would otherwise start at 0 mod 8, and verifies the result.
 
     loop_layout.py fix  in.s out.s      (Makefile: between `hipcc -S --cuda-device-only` and the assembler)
     loop_layout.py check kernels.o      (exit status 1 if a loop of a trace kernel is in the slow phase)
@@ -97,52 +99,87 @@ def assemble(lines, tmp, name):
     return co
 
 
+NOP_AHEAD = 14          # instructions between the inserted s_nop and the first instruction of the 64-bit run
+
+
+def text_loops(lines, marks):
+    """for every FT_LOOP_PHASE marker (line index of its `.rept`): the text lines of the instructions of the loop that follows
+    it, i.e. of the first backward branch after the marker whose body holds 4 v_rsq_f32 (None if there is none before the next marker)"""
+    out = []
+    for j, m in enumerate(marks):
+        stop = marks[j + 1] if j + 1 < len(marks) else len(lines)
+        labels, found = {}, None
+        for i in range(m, stop):
+            lm = re.match(r"(\.LBB\d+_\d+):", lines[i])
+            if lm:
+                labels[lm.group(1)] = i
+            bm = re.match(r"\ts_cbranch_scc\d (\.LBB\d+_\d+)\s*$", lines[i])
+            if bm and bm.group(1) in labels:
+                body = [k for k in range(labels[bm.group(1)], i + 1) if lines[k].startswith("\t") and not lines[k].strip().startswith((";", "."))]
+                if sum(1 for k in body if lines[k].strip().startswith("v_rsq_f32")) == 4:
+                    found = body
+                    break
+        out.append(found)
+    return out
+
+
 def fix(src, dst):
     lines = open(src).read().splitlines()
     marks = [i for i, l in enumerate(lines) if re.match(r"\s*\.rept \d+\s*$", l) and i > 0 and lines[i - 1].strip() == ".p2align 6"]
     if not marks:
         raise SystemExit("loop_layout: no FT_LOOP_PHASE marker in the assembly")
     pads = [0] * len(marks)
+    nops = {}                                                    # marker -> instruction index inside its loop that gets an s_nop in front
 
     def render(with_labels):
         out = list(lines)
+        inserts = []
+        loops = text_loops(lines, marks)
         for j, i in enumerate(marks):
             out[i] = f"\t.rept {pads[j]}"
-        if with_labels:                                        # a symbol per marker: where it landed (objdump -t)
-            for j, i in reversed(list(enumerate(marks))):
-                out.insert(i - 1, f"{MARK}{j}:")
+            if j in nops and loops[j] is not None:
+                inserts.append((loops[j][nops[j]], "\ts_nop 0"))
+            if with_labels:                                      # a symbol per marker: where it landed (objdump -t)
+                inserts.append((i - 1, f"{MARK}{j}:"))
+        for at, text in sorted(inserts, reverse=True):
+            out.insert(at, text)
         return out
 
+    def analyse(tmp):
+        co = assemble(render(True), tmp, "probe")
+        symtab = subprocess.check_output([LLVM + "/llvm-objdump", "-t", co], text=True)
+        where = {int(m.group(2)): int(m.group(1), 16) for m in re.finditer(r"^([0-9a-f]+) .*\b" + MARK + r"(\d+)$", symtab, re.M)}
+        res = []
+        for sym, kind, body in sphere_loops(disassemble(co)):
+            owner = max((j for j, a in where.items() if a <= body[0][0]), key=lambda j: where[j], default=None)
+            if owner is None or body[0][0] - where[owner] > 256:
+                raise SystemExit(f"loop_layout: the {kind} loop at {body[0][0]:#x} of {sym} has no FT_LOOP_PHASE marker in front of it")
+            phase, run = run_phase(body)
+            res.append((owner, sym, kind, body, phase, run))
+        return res
+
     with tempfile.TemporaryDirectory() as tmp:
-        for attempt in range(3):
-            co = assemble(render(True), tmp, "probe")
-            symtab = subprocess.check_output([LLVM + "/llvm-objdump", "-t", co], text=True)
-            where = {int(m.group(2)): int(m.group(1), 16) for m in re.finditer(r"^([0-9a-f]+) .*\b" + MARK + r"(\d+)$", symtab, re.M)}
-            loops = sphere_loops(disassemble(co))
-            slow = []
-            for sym, kind, body in loops:
-                phase, run = run_phase(body)
-                owner = max((j for j, a in where.items() if a <= body[0][0]), key=lambda j: where[j], default=None)
-                if owner is None or body[0][0] - where[owner] > 256:
-                    raise SystemExit(f"loop_layout: the {kind} loop at {body[0][0]:#x} of {sym} has no FT_LOOP_PHASE marker in front of it")
-                if phase != 4:
-                    slow.append(owner)
-            if not slow:
-                break
-            if attempt == 2 or len(set(slow)) != len(slow):
-                raise SystemExit("loop_layout: could not place every loop in the fast phase")
-            for j in slow:
-                pads[j] ^= 1
+        for owner, sym, kind, body, phase, run in analyse(tmp):       # 1: loop heads to 4 mod 8
+            if body[0][0] % 8 != 4:
+                pads[owner] ^= 1
+        for owner, sym, kind, body, phase, run in analyse(tmp):       # 2: runs to 4 mod 8 with one s_nop inside the loop
+            if body[0][0] % 8 != 4:
+                raise SystemExit("loop_layout: could not place a loop head at 4 mod 8")
+            if phase != 4:
+                at = next(k for k, ins in enumerate(body) if ins[0] == run[0][0]) - NOP_AHEAD
+                if at < 1:
+                    raise SystemExit("loop_layout: the 64-bit run starts too early in the loop for the s_nop")
+                nops[owner] = at
         final = render(False)
         co = assemble(final, tmp, "final")
         report = []
         for sym, kind, body in sphere_loops(disassemble(co)):
             phase, run = run_phase(body)
-            report.append(f"{sym}: {kind} loop {len(body)} instr / {body[-1][0] + 4 - body[0][0]} B, 64-bit run of {len(run)} at {run[0][0]:#x} = {phase} mod 8")
-            if phase != 4:
+            report.append(f"{sym}: {kind} loop {len(body)} instr / {body[-1][0] + 4 - body[0][0]} B, head {body[0][0] % 8} mod 8, 64-bit run of {len(run)} at {run[0][0]:#x} = {phase} mod 8")
+            if phase != 4 or body[0][0] % 8 != 4:
                 raise SystemExit("loop_layout: verification failed: " + report[-1])
     open(dst, "w").write("\n".join(final) + "\n")
-    print(f"loop_layout: {len(report)} sphere loops placed in the fast phase (pads {pads})")
+    print(f"loop_layout: {len(report)} sphere loops placed (head and 64-bit run at 4 mod 8; pads {pads}, s_nop in loops {sorted(nops)})")
     return report
 
 
@@ -155,9 +192,10 @@ def check(path, only_trace_kernels=True):
                 continue
             phase, run = run_phase(body)
             n += 1
-            bad += phase != 4
-            print(f"{sym}: {kind} loop at {body[0][0]:#x} ({len(body)} instructions, {body[-1][0] + 4 - body[0][0]} bytes), longest 64-bit VALU run = "
-                  f"{len(run)} instructions at {run[0][0]:#x} = {phase} mod 8 -> {'fast' if phase == 4 else 'SLOW'} phase")
+            ok = phase == 4 and body[0][0] % 8 == 4
+            bad += not ok
+            print(f"{sym}: {kind} loop at {body[0][0]:#x} = {body[0][0] % 8} mod 8 ({len(body)} instructions, {body[-1][0] + 4 - body[0][0]} bytes), longest 64-bit VALU run = "
+                  f"{len(run)} instructions at {run[0][0]:#x} = {phase} mod 8 -> {'fast phase' if ok else ('SLOW phase' if phase != 4 else 'fast phase, head not at 4 mod 8')}")
     if n == 0:
         raise SystemExit("loop_layout: no sphere loop found: the check needs updating")
     return bad
