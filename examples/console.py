@@ -13,8 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import fraytracer_amd as ft
 from fraytracer_amd import synthetic as syn
-from fraytracer_amd.dotnet_random import Random
-from fraytracer_amd.postprocess import toColors, saveBitmap
+from fraytracer_amd.postprocess import saveBitmap
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1000)
@@ -32,6 +31,7 @@ t0 = time.perf_counter()
 traced = ft.Image.render(epsilon, 30.0, imageSize, camera, ft.SdfScene.trace(scene))   # Program.fs:90-93
 print(f"Time = {time.perf_counter() - t0:.2f} sec")                        # Program.fs:96 (includes scene upload)
 
-rng = Random(19)   # the reference keeps drawing from the scene's generator; its dithering is racy anyway
-saveBitmap(args.out, toColors(2.2, rng if args.size <= 256 else None, traced))          # Program.fs:98-100
+# Program.fs:98-100: Image.toColors 2.2f rng |> Image.saveBitmap.  The tone map runs on the GPU (ft_tone_map_host); the reference draws its
+# dithering noise from the scene's generator shared by a parallel map (racy): here it is a counter-based hash seeded with 19.
+saveBitmap(args.out, ft.Image.toColors(2.2, 19, traced))
 print("wrote", args.out)

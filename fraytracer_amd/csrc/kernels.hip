@@ -267,7 +267,7 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 // the loop it measures: [0] loop trips summed over lanes, [1] loop trips per wave x 64, [2] candidate evaluations summed over
 // lanes, [3] candidate-evaluation blocks per wave x 64, [4] shader cycles inside the union walk (per wave), [5] inside the whole
 // scene evaluation, [6] wave-level evaluations x 64, [7] shader cycles of whole rounds (evaluation + state machine + refill)
-__device__ unsigned long long ft_union_dbg[8];
+__device__ unsigned long long ft_union_dbg[10];   // [8] shader cycles a wave waits for the candidate records of a trip, [9] cycles in candidate evaluations
 __device__ __forceinline__ void ft_dbg_add(uint32_t k, uint32_t v) {
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + (7u + k) * FT_BLOCK, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -317,7 +317,12 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     bool first = true;
     while (i < end) {
         const uint32_t j = i + 1u < end ? i + 1u : i;
+        FT_UDBG_T0(tLoad);
         const ItemRegs ra = ld_item(items + i), rb = ld_item(items + j);
+#ifdef FT_UNION_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        FT_UDBG_T1(8, tLoad);
         FT_UDBG(0, 1); FT_UDBG_WAVE(1);
         const float lbA = ra.a.x - distanceToCenter, lbB = rb.a.x - distanceToCenter;
         const float mdA = ft_dist<FQ>(mk3(ra.a.y, ra.a.z, ra.a.w), p) - __uint_as_float(ra.b.x);    // :31 getMinDistance
@@ -332,10 +337,12 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
             typeData = rb.b.y; mat = rb.b.z;                           // evaluate B
         }
         FT_UDBG(2, 1); FT_UDBG_WAVE(3);
+        FT_UDBG_T0(tPrim);
         const uint32_t type = typeData & 15u, data = typeData >> 4;
         float d; uint32_t l;
         if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
         else { d = prim_eval_t<FQ>(type, consts + data, p); l = mat; }
+        FT_UDBG_T1(9, tPrim);
         if (first) { mn = d; leaf = l; first = false; }
         else {
             if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
@@ -914,7 +921,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         if (blockIdx.x == 0 && tid == 0) { atomicAdd(&a.stats->clk_shader, clock64() - clk0[0]); atomicAdd(&a.stats->clk_ref, wall_clock64() - clk0[1]); }
     }
 #ifdef FT_UNION_PROFILE
-    for (uint32_t k = 0; k < 8; ++k) {
+    for (uint32_t k = 0; k < 10; ++k) {
         const unsigned long long v = wave_sum(cw[(7u + k) * FT_BLOCK]);
         if (lane == 0 && v) atomicAdd(&ft_union_dbg[k], v);
     }
@@ -1250,10 +1257,10 @@ extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsig
     return hipGetLastError();
 }
 #ifdef FT_UNION_PROFILE
-extern "C" hipError_t ft_debug_union_counters(unsigned long long out[8]) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 8);
+extern "C" hipError_t ft_debug_union_counters(unsigned long long out[10]) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 10);
     if (e != hipSuccess) return e;
-    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(ft_union_dbg), zero, sizeof(zero));
 }
 #endif

@@ -123,6 +123,14 @@ inline std::vector<float> renderScene(float epsilon, float length, ImageSize siz
     if (stats) *stats = st;
     return out;
 }
+// Image.toColors gamma rng image (Image.fs:37-50) on the GPU: bytes in Color[X,Y] order (R,G,B) or, with bmpOrder, in the scan-line
+// order of Image.toBitmap (Image.fs:61-86: rows from the top, B,G,R).  seed < 0: no dithering noise (the reference's is racy).
+inline std::vector<unsigned char> toColors(ft_ctx* ctx, float gamma, long long seed, const std::vector<float>& image, ImageSize size, bool bmpOrder = false) {
+    std::vector<unsigned char> out((size_t)size.X * size.Y * 3);
+    ft_tonemap_params tm{gamma, seed >= 0 ? 1 : 0, (uint32_t)(seed >= 0 ? seed : 0), bmpOrder ? 1 : 0};
+    check(ft_tone_map_host(ctx, image.data(), size.X, size.Y, &tm, out.data(), nullptr));
+    return out;
+}
 }  // namespace Image
 
 // SdfObject.tryTrace / SdfForm.tryTrace (SdfObject.fs:66-78, SdfForm.fs:93-104) over a ray buffer; hit == 0 is ValueNone

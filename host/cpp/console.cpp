@@ -45,16 +45,13 @@ struct DotNetRandom {
     }
 };
 
-static void saveBitmap(const char* path, const std::vector<float>& img, int X, int Y) {
-    // Image.toColors 2.2 (Image.fs:37-50) without dithering, then Image.toBitmap's orientation (Image.fs:61-86)
-    float mx = 0.01f; for (float v : img) if (v > mx) mx = v;
+static void saveBitmap(const char* path, ft_ctx* ctx, const std::vector<float>& img, int X, int Y) {
+    // Image.toColors 2.2f rng (Image.fs:37-50) and Image.toBitmap's buffer order (Image.fs:61-86) on the GPU (ft_tone_map_host); the
+    // reference's dithering noise is racy, here it is the library's counter-based hash seeded with 19.  BMP rows are stored bottom-up.
+    const std::vector<unsigned char> rows = Image::toColors(ctx, 2.2f, 19, img, ImageSize{X, Y}, true);
     const int stride = (3 * X + 3) & ~3;
     std::vector<unsigned char> body((size_t)stride * Y, 0);
-    for (int r = 0; r < Y; ++r) for (int c = 0; c < X; ++c) {
-        const float* px = &img[3 * ((size_t)(X - 1 - c) * Y + r)];
-        unsigned char* o = &body[(size_t)(Y - 1 - r) * stride + 3 * c];
-        for (int k = 0; k < 3; ++k) { float v = std::nearbyint(powf(px[k] / mx, 1.0f / 2.2f) * 254.5f + 0.5f); o[2 - k] = (unsigned char)(v > 255 ? 255 : v); }
-    }
+    for (int r = 0; r < Y; ++r) memcpy(&body[(size_t)(Y - 1 - r) * stride], &rows[(size_t)r * X * 3], (size_t)X * 3);
     unsigned char h[54] = {'B', 'M'};
     auto put = [&](int at, unsigned v) { memcpy(h + at, &v, 4); };
     put(2, 54 + (unsigned)body.size()); put(10, 54); put(14, 40); put(18, X); put(22, Y); h[26] = 1; h[28] = 24; put(34, (unsigned)body.size());
@@ -99,7 +96,7 @@ int main(int argc, char** argv) {
         printf("rays %llu primary + %llu shadow, kernel %.3f ms, %.1f Mrays/s (kernel)\n", (unsigned long long)st.rays_primary,
                (unsigned long long)st.rays_shadow, st.kernel_ms, (st.rays_primary + st.rays_shadow) / (st.kernel_ms * 1e3));
         if (raw) { FILE* f = fopen(raw, "wb"); if (f) { fwrite(traced.data(), 4, traced.size(), f); fclose(f); } }
-        saveBitmap(out, traced, size, size);                                               // Program.fs:98-100
+        saveBitmap(out, ctx.get(), traced, size, size);                                               // Program.fs:98-100
     } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     return 0;
 }

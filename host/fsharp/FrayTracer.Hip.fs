@@ -39,6 +39,11 @@ type FtCamera =
     static member ofCamera (c : Camera) : FtCamera =
         { Position = c.Position; Forward = c.Forward; UpScaled = c.UpScaled; RightScaled = c.RightScaled }
 
+/// ft_tonemap_params (16 B): Image.toColors' gamma; Dither = 0 -> no noise (u = 0.5), 1 -> counter-based hash of (x, y, channel, Seed);
+/// BmpOrder = 1 -> the scan0 buffer Image.toBitmap builds (Image.fs:61-86) instead of Color[X,Y] as R,G,B bytes
+[<Struct; StructLayout(LayoutKind.Sequential)>]
+type FtTonemapParams = { Gamma : float32; Dither : int; Seed : uint32; BmpOrder : int }
+
 /// ft_form_trace_result: SdfFormTraceResult voption (Types.fs:32-37), Hit = 0 is ValueNone
 [<Struct; StructLayout(LayoutKind.Sequential)>]
 type FtFormTraceResult = { Ray : Ray; Distance : float32; Hit : int }
@@ -79,6 +84,12 @@ module Native =
     [<DllImport(Lib)>] extern int ft_form_try_trace(nativeint ctx, nativeint scene, Ray[] rays, int64 n, [<Out>] FtFormTraceResult[] out, FtStats& stats)
     [<DllImport(Lib)>] extern int ft_object_try_trace(nativeint ctx, nativeint scene, Ray[] rays, int64 n, [<Out>] FtObjectTraceResult[] out, FtStats& stats)
     [<DllImport(Lib)>] extern int ft_render(nativeint ctx, nativeint scene, FtCamera& camera, FtRenderParams& p, nativeint out, FtStats& stats)
+    // a destination that is reused over many frames can be page-locked once (otherwise ft_render pins it for the duration of each call)
+    [<DllImport(Lib)>] extern int ft_host_register(nativeint ctx, nativeint p, uint64 bytes)
+    [<DllImport(Lib)>] extern int ft_host_unregister(nativeint ctx, nativeint p)
+    // Image.toColors on the GPU: host FColor[,] in, bytes out / render + tone map in one call (only 3 bytes per pixel cross PCIe)
+    [<DllImport(Lib)>] extern int ft_tone_map_host(nativeint ctx, nativeint frame, int X, int Y, FtTonemapParams& p, nativeint out, float32& maxOut)
+    [<DllImport(Lib)>] extern int ft_render_colors(nativeint ctx, nativeint scene, FtCamera& camera, FtRenderParams& p, FtTonemapParams& tm, nativeint out, float32& maxOut, FtStats& stats)
 
     /// one context for the process (GPU 0); there is no CPU fallback inside the library
     let ctx =
@@ -247,6 +258,21 @@ module Image =
                 pin.Free ()
         finally
             Native.ft_scene_destroy handle
+
+    /// GPU sibling of `image |> Image.toColors gamma rng` (Image.fs:37-50).  The reference draws its dithering noise from one
+    /// System.Random shared by a parallel map (racy); here `seed = ValueNone` means no noise, `ValueSome s` a counter-based hash.
+    let toColors (gamma : float32) (seed : uint32 voption) (image : FColor[,]) : System.Drawing.Color[,] =
+        let X, Y = image.GetLength 0, image.GetLength 1
+        let bytes : byte[] = Array.zeroCreate (X * Y * 3)
+        let pinIn = GCHandle.Alloc (image, GCHandleType.Pinned)
+        let pinOut = GCHandle.Alloc (bytes, GCHandleType.Pinned)
+        try
+            let mutable tm = { Gamma = gamma; Dither = (if seed.IsSome then 1 else 0); Seed = (match seed with ValueSome s -> s | ValueNone -> 0u); BmpOrder = 0 }
+            let mutable mx = 0f
+            Native.check (Native.ft_tone_map_host (Native.ctx.Value, pinIn.AddrOfPinnedObject (), X, Y, &tm, pinOut.AddrOfPinnedObject (), &mx)) |> ignore
+            Array2D.init X Y (fun x y -> let i = (x * Y + y) * 3 in System.Drawing.Color.FromArgb (int bytes.[i], int bytes.[i + 1], int bytes.[i + 2]))
+        finally
+            pinOut.Free (); pinIn.Free ()
 
     /// the CPU path of the reference on the same scene value (closures)
     let renderSceneCpu (epsilon : float32) (length : float32) (imageSize : ImageSize) (camera : Camera) (scene : GpuScene) =
