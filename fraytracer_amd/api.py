@@ -316,7 +316,7 @@ class Device:
     introspection only — rendering raises, there is no CPU fallback)."""
 
     _default = {}
-    _default_lock = threading.Lock()
+    _default_lock = threading.RLock()          # re-entrant: default() constructs a Device, whose __init__ takes the lock for its serial
     _serial = 0
 
     def __init__(self, index=0):

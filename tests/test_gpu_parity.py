@@ -612,6 +612,22 @@ def test_nan_distances_are_flagged_identically(gpu, oracle):
         assert s1["flags"] == 0 and tuple(g1[0]) != tuple(np.float32(syn.BACKGROUND))
 
 
+def test_default_device_paths(oracle):
+    """the calls that name no device — `Image.render eps len size camera (SdfScene.trace scene)`, `Image.toColors`, `SdfObject.tryTrace` — run on
+    the process-wide default context of GPU 0 (examples/console.py uses exactly these)"""
+    scene, _ = syn.config2(seed=3)
+    cam = syn.default_camera()
+    img = ft.Image.render(EPS, LEN, ft.ImageSize(64, 48), cam, ft.SdfScene.trace(scene))
+    want, _ = oracle.Oracle().scene(scene).render(EPS, LEN, 64, 48, cam.as_array())
+    assert_bit_equal(img, want, "Image.render on the default device")
+    cols = ft.Image.toColors(2.2, 19, img)
+    wcols, _ = oracle.tone_map(img, gamma=2.2, seed=19)
+    assert np.array_equal(cols, wcols)
+    rays = np.stack([oracle.pixel_ray(cam.as_array(), 64, 48, x, 24, EPS, LEN) for x in range(64)])
+    assert_bit_equal(ft.SdfScene.trace(scene)(rays[32]), img[32, 24], "SdfScene.trace scene ray")
+    assert ft.Device.default(0) is ft.Device.default(0)
+
+
 def test_empty_and_degenerate_inputs(gpu, oracle):
     scene, _ = syn.config1()
     ds, os_ = both(gpu, oracle, scene)
