@@ -45,8 +45,24 @@ def render(name):
     return img, counts, np.array([W, H], np.int32)
 
 
+# Tone map fixture: the oracle's Image.toColors / toBitmap bytes of two golden images, plain and with noise
+TONEMAP = {"tonemap_console_like_300_64": "console_like_300_64", "tonemap_c3_smooth256_48": "c3_smooth256_48"}
+
+
+def tonemap(name):
+    img = np.load(os.path.join(HERE, TONEMAP[name] + ".npz"), allow_pickle=False)["image"]
+    plain, mx = ob.tone_map(img, gamma=2.2)
+    noisy_bmp, _ = ob.tone_map(img, gamma=2.2, seed=19, bmp_order=True)
+    return plain, noisy_bmp, np.float32(mx)
+
+
 if __name__ == "__main__":
-    for name in (sys.argv[1:] or CASES):
+    for name in (sys.argv[1:] or list(CASES) + list(TONEMAP)):
+        if name in TONEMAP:
+            plain, noisy_bmp, mx = tonemap(name)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), plain=plain, noisy_bmp=noisy_bmp, max=mx)
+            print(name, plain.shape, noisy_bmp.shape, float(mx))
+            continue
         img, counts, size = render(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, counts=counts, size=size,
                             epsilon=np.float32(syn.EPSILON), length=np.float32(syn.RAY_LENGTH))

@@ -41,3 +41,19 @@ def test_hip_reproduces_golden(gpu, name):
     assert_bit_equal(img, want, name)
     got = [st["rays_primary"], st["rays_shadow"], st["hits_primary"], st["hits_shadow"], st["flags"]] + ([st["rays_ext"]] if ext else [])
     assert got == counts.tolist()
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.TONEMAP))
+def test_oracle_reproduces_golden_tone_map(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    plain, noisy_bmp, mx = make_golden.tonemap(name)
+    assert np.array_equal(plain, z["plain"]) and np.array_equal(noisy_bmp, z["noisy_bmp"]) and mx == z["max"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(make_golden.TONEMAP))
+def test_hip_reproduces_golden_tone_map(gpu, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    img = np.load(os.path.join(GOLDEN, make_golden.TONEMAP[name] + ".npz"), allow_pickle=False)["image"]
+    assert np.array_equal(ft.Image.toColors(2.2, None, img, gpu), z["plain"])
+    assert np.array_equal(ft.Image.toColors(2.2, 19, img, gpu, bmp_order=True), z["noisy_bmp"])
