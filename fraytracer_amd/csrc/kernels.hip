@@ -214,7 +214,13 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 // one a plain compile produces depends on the dword count of the code in front.  FT_LOOP_PHASE marks the spot: the build's
 // layout pass (csrc/loop_layout.py, run by the Makefile on the device assembly) sets the number of s_nops behind the
 // 64-byte boundary to 0 or 1 per loop so that every loop lands in the fast phase, and verifies it in the disassembly.
-#define FT_LOOP_PHASE() asm volatile(".p2align 6\n\t.rept 0\n\ts_nop 0\n\t.endr" ::: "memory")
+// FT_LOOP_PAD: the s_nop count of a build WITHOUT the pass (tools/pad_sweep_build.sh sweeps it; the pass overwrites it).
+#ifndef FT_LOOP_PAD
+#define FT_LOOP_PAD 0
+#endif
+#define FT_STR2(x) #x
+#define FT_STR(x) FT_STR2(x)
+#define FT_LOOP_PHASE() asm volatile(".p2align 6\n\t.rept " FT_STR(FT_LOOP_PAD) "\n\ts_nop 0\n\t.endr" ::: "memory")
 
 template <bool NEAR>
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
