@@ -582,16 +582,24 @@ int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_rende
     std::vector<int> c0(nChunks + 1);
     for (int i = 0; i < nChunks; ++i) c0[i] = (int)(((int64_t)p->n_columns * i / nChunks) & ~(int64_t)7);   // chunks start on a tile boundary
     c0[nChunks] = p->n_columns;
+    bool pinnedHere = false;
+    // whatever goes wrong, nothing of this call may still be in flight when it returns (the scratch frame and the caller's
+    // buffer are reused), and a buffer pinned here is released
+    auto finish = [&](int code) {
+        (void)hipStreamSynchronize(c->copyStream); (void)hipStreamSynchronize(c->lane1); (void)hipStreamSynchronize(c->stream);
+        if (pinnedHere) (void)hipHostUnregister(out);
+        return code;
+    };
     for (int i = 0; i < nChunks; ++i) {
         ft_render_params q = *p;
         q.x0 = p->x0 + c0[i]; q.n_columns = c0[i + 1] - c0[i];
         if (p->stripe_ranks == 1) q.stripe_width = q.n_columns;
         const int lane = nChunks > 1 ? (i & 1) : 0;
-        if ((rc = renderLane(c, s, cam, &q, dFrame + (size_t)c0[i] * colBytes, lane))) return rc;
-        HIP_TRY(hipEventRecord(c->syncEvents[2 + i], lane ? c->lane1 : c->stream));
+        if ((rc = renderLane(c, s, cam, &q, dFrame + (size_t)c0[i] * colBytes, lane))) return finish(rc);
+        const hipError_t e = hipEventRecord(c->syncEvents[2 + i], lane ? c->lane1 : c->stream);
+        if (e != hipSuccess) return finish(hipFail(e, "hipEventRecord"));
     }
     // the GPU is rendering: page-lock the destination meanwhile
-    bool pinnedHere = false;
     if (wantPin && !isPageLocked(c, out, bytes)) {
         const hipError_t e = hipHostRegister(out, bytes, hipHostRegisterDefault);
         if (e == hipSuccess) pinnedHere = true; else (void)hipGetLastError();    // not fatal: the runtime's pageable path still works
@@ -607,8 +615,8 @@ int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_rende
     if (err == hipSuccess) err = hipStreamSynchronize(c->copyStream);
     if (err == hipSuccess) err = hipStreamSynchronize(c->lane1);
     if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
-    if (pinnedHere) (void)hipHostUnregister(out);
-    if (err != hipSuccess) return hipFail(err, "ft_render host output");
+    if (err != hipSuccess) return finish(hipFail(err, "ft_render host output"));
+    if (pinnedHere) { (void)hipHostUnregister(out); pinnedHere = false; }
     return ft_collect_stats(c, st);
 }
 

@@ -107,7 +107,11 @@ def test_errors_are_reported_not_swallowed(host):
     for call in (lambda: ds.trace_rays(rays), lambda: ds.form_try_trace(rays), lambda: ds.object_try_trace(rays),
                  lambda: ds.eval_distance(np.zeros((4, 3), np.float32)), lambda: ds.collect_stats(),
                  lambda: host.math_eval(0, np.zeros(4, np.float32)), lambda: host.selftest_fastmath(),
-                 lambda: ds.render(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera(), spp=4, max_bounces=2, spectral=4)):
+                 lambda: ds.render(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera(), spp=4, max_bounces=2, spectral=4),
+                 lambda: ds.render_colors(0.01, 30.0, ft.ImageSize(8, 8), syn.default_camera()),
+                 lambda: ft.Image.toColors(2.2, None, np.zeros((4, 4, 3), np.float32), host),
+                 lambda: ft.api.tone_map_device(host, 4096, 4, 4),
+                 lambda: host.host_register(np.zeros(1024, np.float32)), lambda: host.host_unregister(np.zeros(4, np.float32))):
         with pytest.raises(ft.FrayTracerError) as e:
             call()
         assert e.value.code == ft._lib.FT_ERR_NO_DEVICE
