@@ -562,56 +562,73 @@ int ensurePipeline(ft_ctx* c, size_t nEvents) {
 
 }  // namespace
 
+namespace {
+
+// The frame of `p` rendered into the context's scratch buffer in column chunks on the two render lanes (the drain of one chunk
+// overlaps the start of the next); chunk i's completion is syncEvents[2 + i].  c0 receives the chunk boundaries (columns).
+struct ChunkPlan { int n = 1; std::vector<int> c0; size_t colBytes = 0, bytes = 0; };
+
+int launchChunks(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, ChunkPlan& plan) {
+    int rc;
+    plan.colBytes = (size_t)p->height * 3 * sizeof(float);
+    plan.bytes = (size_t)p->n_columns * plan.colBytes;
+    if ((rc = ensureScratch(c, plan.bytes))) return rc;
+    // chunks: only the reference's sampling (spp = 1: no shared sample planes) of a contiguous column range that is worth it
+    plan.n = (p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 256 && plan.bytes >= ((size_t)16 << 20)) ? 4 : 1;
+    if (const char* e = getenv("FT_HOST_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 8 * v) plan.n = v; }   // experiments
+    if ((rc = ensurePipeline(c, (size_t)plan.n + 2))) return rc;
+    HIP_TRY(hipEventRecord(c->syncEvents[0], c->stream));      // whatever the caller queued on the context's stream comes first
+    HIP_TRY(hipStreamWaitEvent(c->lane1, c->syncEvents[0], 0));
+    HIP_TRY(hipStreamWaitEvent(c->copyStream, c->syncEvents[0], 0));
+    plan.c0.assign(plan.n + 1, 0);
+    for (int i = 0; i < plan.n; ++i) plan.c0[i] = (int)(((int64_t)p->n_columns * i / plan.n) & ~(int64_t)7);   // chunks start on a tile boundary
+    plan.c0[plan.n] = p->n_columns;
+    char* dFrame = static_cast<char*>(c->scratch);
+    for (int i = 0; i < plan.n; ++i) {
+        ft_render_params q = *p;
+        q.x0 = p->x0 + plan.c0[i]; q.n_columns = plan.c0[i + 1] - plan.c0[i];
+        if (p->stripe_ranks == 1) q.stripe_width = q.n_columns;
+        const int lane = plan.n > 1 ? (i & 1) : 0;
+        if ((rc = renderLane(c, s, cam, &q, dFrame + (size_t)plan.c0[i] * plan.colBytes, lane))) return rc;
+        HIP_TRY(hipEventRecord(c->syncEvents[2 + i], lane ? c->lane1 : c->stream));
+    }
+    return FT_OK;
+}
+
+void drainPipeline(ft_ctx* c) {
+    (void)hipStreamSynchronize(c->copyStream); (void)hipStreamSynchronize(c->lane1); (void)hipStreamSynchronize(c->stream);
+}
+
+// page-lock `p` unless it already is; true if this call pinned it (the caller unpins)
+bool pinForCall(ft_ctx* c, void* p, size_t bytes) {
+    if (bytes < ((size_t)1 << 20) || getenv("FT_HOST_NO_PIN") || isPageLocked(c, p, bytes)) return false;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) return true;
+    (void)hipGetLastError();                                   // not fatal: the runtime's pageable path still works
+    return false;
+}
+
+}  // namespace
+
 int ft_render(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_render_params* p, float* out, ft_stats* st) {
     int rc = requireDevice(c); if (rc) return rc;
     if (!out) return setErr(FT_ERR_INVALID, "null output");
     if ((rc = checkParams(p))) return rc;
-    const size_t colBytes = (size_t)p->height * 3 * sizeof(float);
-    const size_t bytes = (size_t)p->n_columns * colBytes;
-    if ((rc = ensureScratch(c, bytes))) return rc;
-    char* dFrame = static_cast<char*>(c->scratch);
-    // chunks: only the reference's sampling (spp = 1: no shared sample planes) of a contiguous column range that is worth it
-    int nChunks = (p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 256 && bytes >= ((size_t)16 << 20)) ? 4 : 1;
-    if (const char* e = getenv("FT_HOST_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 8 * v) nChunks = v; }   // experiments
-    const bool wantPin = bytes >= ((size_t)1 << 20) && !getenv("FT_HOST_NO_PIN");
-    if ((rc = ensurePipeline(c, (size_t)nChunks + 2))) return rc;
-    hipEvent_t evStart = c->syncEvents[0], evCopied = c->syncEvents[1];
-    HIP_TRY(hipEventRecord(evStart, c->stream));               // whatever the caller queued on the context's stream comes first
-    HIP_TRY(hipStreamWaitEvent(c->lane1, evStart, 0));
-    HIP_TRY(hipStreamWaitEvent(c->copyStream, evStart, 0));
-    std::vector<int> c0(nChunks + 1);
-    for (int i = 0; i < nChunks; ++i) c0[i] = (int)(((int64_t)p->n_columns * i / nChunks) & ~(int64_t)7);   // chunks start on a tile boundary
-    c0[nChunks] = p->n_columns;
+    ChunkPlan plan;
     bool pinnedHere = false;
     // whatever goes wrong, nothing of this call may still be in flight when it returns (the scratch frame and the caller's
     // buffer are reused), and a buffer pinned here is released
-    auto finish = [&](int code) {
-        (void)hipStreamSynchronize(c->copyStream); (void)hipStreamSynchronize(c->lane1); (void)hipStreamSynchronize(c->stream);
-        if (pinnedHere) (void)hipHostUnregister(out);
-        return code;
-    };
-    for (int i = 0; i < nChunks; ++i) {
-        ft_render_params q = *p;
-        q.x0 = p->x0 + c0[i]; q.n_columns = c0[i + 1] - c0[i];
-        if (p->stripe_ranks == 1) q.stripe_width = q.n_columns;
-        const int lane = nChunks > 1 ? (i & 1) : 0;
-        if ((rc = renderLane(c, s, cam, &q, dFrame + (size_t)c0[i] * colBytes, lane))) return finish(rc);
-        const hipError_t e = hipEventRecord(c->syncEvents[2 + i], lane ? c->lane1 : c->stream);
-        if (e != hipSuccess) return finish(hipFail(e, "hipEventRecord"));
-    }
-    // the GPU is rendering: page-lock the destination meanwhile
-    if (wantPin && !isPageLocked(c, out, bytes)) {
-        const hipError_t e = hipHostRegister(out, bytes, hipHostRegisterDefault);
-        if (e == hipSuccess) pinnedHere = true; else (void)hipGetLastError();    // not fatal: the runtime's pageable path still works
-    }
+    auto finish = [&](int code) { if (c->copyStream) drainPipeline(c); if (pinnedHere) (void)hipHostUnregister(out); return code; };
+    if ((rc = launchChunks(c, s, cam, p, plan))) return finish(rc);
+    pinnedHere = pinForCall(c, out, plan.bytes);               // the GPU is rendering: page-lock the destination meanwhile
+    char* dFrame = static_cast<char*>(c->scratch);
     hipError_t err = hipSuccess;
-    for (int i = 0; i < nChunks && err == hipSuccess; ++i) {
-        const size_t off = (size_t)c0[i] * colBytes, n = (size_t)(c0[i + 1] - c0[i]) * colBytes;
+    for (int i = 0; i < plan.n && err == hipSuccess; ++i) {
+        const size_t off = (size_t)plan.c0[i] * plan.colBytes, n = (size_t)(plan.c0[i + 1] - plan.c0[i]) * plan.colBytes;
         if ((err = hipStreamWaitEvent(c->copyStream, c->syncEvents[2 + i], 0)) != hipSuccess) break;
         err = hipMemcpyAsync(reinterpret_cast<char*>(out) + off, dFrame + off, n, hipMemcpyDeviceToHost, c->copyStream);
     }
-    if (err == hipSuccess) err = hipEventRecord(evCopied, c->copyStream);
-    if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, evCopied, 0);          // join: the context's stream ends after the copies
+    if (err == hipSuccess) err = hipEventRecord(c->syncEvents[1], c->copyStream);
+    if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->syncEvents[1], 0);   // join: the context's stream ends after the copies
     if (err == hipSuccess) err = hipStreamSynchronize(c->copyStream);
     if (err == hipSuccess) err = hipStreamSynchronize(c->lane1);
     if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
@@ -670,10 +687,20 @@ int ft_render_colors(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const f
     if ((rc = checkParams(p))) return rc;
     if (p->x0 != 0 || p->n_columns != p->width || p->stripe_ranks != 1)
         return setErr(FT_ERR_INVALID, "the tone map needs the whole frame (its normalisation is the global maximum, Image.fs:40-43)");
-    const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
-    if ((rc = ensureScratch(c, bytes))) return rc;
-    if ((rc = ft_render_device(c, s, cam, p, c->scratch))) return rc;
-    if ((rc = ft_tone_map(c, c->scratch, p->width, p->height, tm, out, max_out))) return rc;
+    if ((rc = checkToneMap(out, p->width, p->height, tm))) return rc;
+    // the frame is rendered like ft_render's (column chunks on two lanes); the tone map follows on the context's stream once both
+    // lanes are done — its normalisation needs every pixel — and only the bytes are copied out
+    ChunkPlan plan;
+    const size_t outBytes = (size_t)p->width * p->height * 3;
+    bool pinnedHere = false;
+    auto finish = [&](int code) { if (c->copyStream) drainPipeline(c); if (pinnedHere) (void)hipHostUnregister(out); return code; };
+    if ((rc = launchChunks(c, s, cam, p, plan))) return finish(rc);
+    pinnedHere = pinForCall(c, out, outBytes);
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < plan.n && err == hipSuccess; ++i) err = hipStreamWaitEvent(c->stream, c->syncEvents[2 + i], 0);
+    if (err != hipSuccess) return finish(hipFail(err, "ft_render_colors"));
+    if ((rc = ft_tone_map(c, c->scratch, p->width, p->height, tm, out, max_out))) return finish(rc);
+    if (pinnedHere) { (void)hipHostUnregister(out); pinnedHere = false; }
     return ft_collect_stats(c, st);
 }
 
