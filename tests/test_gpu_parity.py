@@ -324,27 +324,6 @@ def test_render_multi_single_process_path(gpu):
         other.close()
 
 
-def test_render_multi_over_rccl_when_two_devices_exist(gpu):
-    """ft_render_multi's real branch — one host thread per device, ncclGather over xGMI into the first device, strided
-    de-interleave there, one copy out — needs two distinct GPUs: skipped on a one-GPU box, run wherever the suite meets
-    two or more (the one-GPU rehearsal above takes the same code path except for the collective itself)."""
-    try:
-        second = ft.Device(1)
-    except ft.FrayTracerError:
-        pytest.skip("needs at least two GPUs")
-    try:
-        scene, _ = syn.config2(seed=8)
-        cam = syn.default_camera()
-        W, H = 256, 144
-        full, st = gpu.scene(scene).render(EPS, LEN, ft.ImageSize(W, H), cam)
-        for stripe in (16, 64):
-            img, stn = ft.render_multi([gpu, second], scene, EPS, LEN, ft.ImageSize(W, H), cam, stripe_width=stripe)
-            assert_bit_equal(img, full, f"ft_render_multi over 2 GPUs, stripes of {stripe}")
-            assert stn["rays_primary"] == st["rays_primary"] and stn["rays_shadow"] == st["rays_shadow"]
-    finally:
-        second.close()
-
-
 # ---- EXTENSIONS (no reference counterpart; checked against the oracle's own definition only) ------------
 @pytest.mark.parametrize("spp,ao", [(4, 0), (1, 8), (4, 16), (9, 3)])
 def test_extension_spp_and_ambient_occlusion(gpu, oracle, spp, ao):
@@ -856,3 +835,25 @@ def test_union_fast_sqrt_clamp_points(gpu, oracle):
         O = oracle.Oracle()
         with np.errstate(all="ignore"):
             assert_bit_equal(d, O.form_distance(O.object_form(os_.object), pts), f"union fast-sqrt, {factory.__name__}")
+
+
+# ---- last on purpose: needs two GPUs, i.e. it never ran on the one-GPU development boxes -------------------------------
+def test_render_multi_over_rccl_when_two_devices_exist(gpu):
+    """ft_render_multi's real branch — one host thread per device, ncclGather over xGMI into the first device, strided
+    de-interleave there, one copy out — needs two distinct GPUs: skipped on a one-GPU box, run wherever the suite meets
+    two or more (the one-GPU rehearsal above takes the same code path except for the collective itself)."""
+    try:
+        second = ft.Device(1)
+    except ft.FrayTracerError:
+        pytest.skip("needs at least two GPUs")
+    try:
+        scene, _ = syn.config2(seed=8)
+        cam = syn.default_camera()
+        W, H = 256, 144
+        full, st = gpu.scene(scene).render(EPS, LEN, ft.ImageSize(W, H), cam)
+        for stripe in (16, 64):
+            img, stn = ft.render_multi([gpu, second], scene, EPS, LEN, ft.ImageSize(W, H), cam, stripe_width=stripe)
+            assert_bit_equal(img, full, f"ft_render_multi over 2 GPUs, stripes of {stripe}")
+            assert stn["rays_primary"] == st["rays_primary"] and stn["rays_shadow"] == st["rays_shadow"]
+    finally:
+        second.close()
