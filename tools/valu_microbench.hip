@@ -87,6 +87,106 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, float see
                 asm volatile("v_mul_f32 %0, 0x3fb8aa3b, %0\n v_mul_f32 %1, 0x3fb8aa3b, %1\n v_mul_f32 %2, 0x3fb8aa3b, %2\n v_mul_f32 %3, 0x3fb8aa3b, %3\n"
                              "v_mul_f32 %4, 0x3fb8aa3b, %4\n v_mul_f32 %5, 0x3fb8aa3b, %5\n v_mul_f32 %6, 0x3fb8aa3b, %6\n v_mul_f32 %7, 0x3fb8aa3b, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 19) {  // v_max_f32 literal
+                asm volatile("v_max_f32 %0, 0x0f800000, %0\n v_max_f32 %1, 0x0f800000, %1\n v_max_f32 %2, 0x0f800000, %2\n v_max_f32 %3, 0x0f800000, %3\n"
+                             "v_max_f32 %4, 0x0f800000, %4\n v_max_f32 %5, 0x0f800000, %5\n v_max_f32 %6, 0x0f800000, %6\n v_max_f32 %7, 0x0f800000, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 20) {  // v_add_f32 literal
+                asm volatile("v_add_f32 %0, 0x05800000, %0\n v_add_f32 %1, 0x05800000, %1\n v_add_f32 %2, 0x05800000, %2\n v_add_f32 %3, 0x05800000, %3\n"
+                             "v_add_f32 %4, 0x05800000, %4\n v_add_f32 %5, 0x05800000, %5\n v_add_f32 %6, 0x05800000, %6\n v_add_f32 %7, 0x05800000, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 21) {  // v_mad_u32_u24
+                asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n"
+                             "v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 22) {  // v_add_u32
+                asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                             "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 23) {  // v_lshlrev_b32
+                asm volatile("v_lshlrev_b32 %0, 23, %0\n v_lshlrev_b32 %1, 23, %1\n v_lshlrev_b32 %2, 23, %2\n v_lshlrev_b32 %3, 23, %3\n"
+                             "v_lshlrev_b32 %4, 23, %4\n v_lshlrev_b32 %5, 23, %5\n v_lshlrev_b32 %6, 23, %6\n v_lshlrev_b32 %7, 23, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 24) {  // v_mul_u32_u24
+                asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n"
+                             "v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 25) {  // v_and_b32
+                asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                             "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 26) {  // v_add_lshl_u32
+                asm volatile("v_add_lshl_u32 %0, %0, %8, 23\n v_add_lshl_u32 %1, %1, %8, 23\n v_add_lshl_u32 %2, %2, %8, 23\n v_add_lshl_u32 %3, %3, %8, 23\n"
+                             "v_add_lshl_u32 %4, %4, %8, 23\n v_add_lshl_u32 %5, %5, %8, 23\n v_add_lshl_u32 %6, %6, %8, 23\n v_add_lshl_u32 %7, %7, %8, 23"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 27) {  // v_med3_f32
+                asm volatile("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+                             "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 28) {  // v_bfi_b32
+                asm volatile("v_bfi_b32 %0, %8, %0, %9\n v_bfi_b32 %1, %8, %1, %9\n v_bfi_b32 %2, %8, %2, %9\n v_bfi_b32 %3, %8, %3, %9\n"
+                             "v_bfi_b32 %4, %8, %4, %9\n v_bfi_b32 %5, %8, %5, %9\n v_bfi_b32 %6, %8, %6, %9\n v_bfi_b32 %7, %8, %7, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 29) {  // v_mul_f32 omod
+                asm volatile("v_mul_f32_e64 %0, %0, %8 mul:2\n v_mul_f32_e64 %1, %1, %8 mul:2\n v_mul_f32_e64 %2, %2, %8 mul:2\n v_mul_f32_e64 %3, %3, %8 mul:2\n"
+                             "v_mul_f32_e64 %4, %4, %8 mul:2\n v_mul_f32_e64 %5, %5, %8 mul:2\n v_mul_f32_e64 %6, %6, %8 mul:2\n v_mul_f32_e64 %7, %7, %8 mul:2"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 30) {  // v_max_f32 vgpr
+                asm volatile("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                             "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 31) {  // v_mad_u64_u32?
+                asm volatile("v_alignbit_b32 %0, %0, %8, 9\n v_alignbit_b32 %1, %1, %8, 9\n v_alignbit_b32 %2, %2, %8, 9\n v_alignbit_b32 %3, %3, %8, 9\n"
+                             "v_alignbit_b32 %4, %4, %8, 9\n v_alignbit_b32 %5, %5, %8, 9\n v_alignbit_b32 %6, %6, %8, 9\n v_alignbit_b32 %7, %7, %8, 9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 32) {  // v_add3_u32
+                asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n"
+                             "v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 33) {  // v_lshl_or_b32
+                asm volatile("v_lshl_or_b32 %0, %0, 23, %8\n v_lshl_or_b32 %1, %1, 23, %8\n v_lshl_or_b32 %2, %2, 23, %8\n v_lshl_or_b32 %3, %3, 23, %8\n"
+                             "v_lshl_or_b32 %4, %4, 23, %8\n v_lshl_or_b32 %5, %5, 23, %8\n v_lshl_or_b32 %6, %6, 23, %8\n v_lshl_or_b32 %7, %7, 23, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 34) {  // v_sub_f32 vgpr
+                asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
+                             "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 35) {  // v_mul_f32 vgpr
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 36) {  // v_fma_f32 neg
+                asm volatile("v_fma_f32 %0, -%0, %8, %9\n v_fma_f32 %1, -%1, %8, %9\n v_fma_f32 %2, -%2, %8, %9\n v_fma_f32 %3, -%3, %8, %9\n"
+                             "v_fma_f32 %4, -%4, %8, %9\n v_fma_f32 %5, -%5, %8, %9\n v_fma_f32 %6, -%6, %8, %9\n v_fma_f32 %7, -%7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 37) {  // v_rcp_f32
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 38) {  // v_exp_f32
+                asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                             "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 39) {  // v_mov_b32
+                asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
+                             "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 40) {  // v_xad_u32
+                asm volatile("v_xad_u32 %0, %0, %8, %9\n v_xad_u32 %1, %1, %8, %9\n v_xad_u32 %2, %2, %8, %9\n v_xad_u32 %3, %3, %8, %9\n"
+                             "v_xad_u32 %4, %4, %8, %9\n v_xad_u32 %5, %5, %8, %9\n v_xad_u32 %6, %6, %8, %9\n v_xad_u32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 41) {  // v_pk_mad_u16
+                asm volatile("v_pk_mad_u16 %0, %0, %8, %9 op_sel_hi:[0,1,1]\n v_pk_mad_u16 %1, %1, %8, %9 op_sel_hi:[0,1,1]\n v_pk_mad_u16 %2, %2, %8, %9 op_sel_hi:[0,1,1]\n v_pk_mad_u16 %3, %3, %8, %9 op_sel_hi:[0,1,1]\n"
+                             "v_pk_mad_u16 %4, %4, %8, %9 op_sel_hi:[0,1,1]\n v_pk_mad_u16 %5, %5, %8, %9 op_sel_hi:[0,1,1]\n v_pk_mad_u16 %6, %6, %8, %9 op_sel_hi:[0,1,1]\n v_pk_mad_u16 %7, %7, %8, %9 op_sel_hi:[0,1,1]"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 42) {  // v_pk_add_u16
+                asm volatile("v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n"
+                             "v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 43) {  // v_mad_u32_u16
+                asm volatile("v_mad_u32_u16 %0, %0, %8, %9\n v_mad_u32_u16 %1, %1, %8, %9\n v_mad_u32_u16 %2, %2, %8, %9\n v_mad_u32_u16 %3, %3, %8, %9\n"
+                             "v_mad_u32_u16 %4, %4, %8, %9\n v_mad_u32_u16 %5, %5, %8, %9\n v_mad_u32_u16 %6, %6, %8, %9\n v_mad_u32_u16 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
             } else if (OP == 9) {  // v_fma_f64
                 asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
                              "v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5"
@@ -126,6 +226,8 @@ int main() {
     run<10>("v_fmaak lit", 8, cus, d); run<11>("v_fma inline.5", 8, cus, d); run<12>("v_lshl_add_u32", 8, cus, d);
     run<13>("v_cmp_nle_f32", 8, cus, d); run<14>("v_min3_u32", 8, cus, d); run<15>("v_fmac_f32", 8, cus, d);
     run<16>("v_fma sgpr", 8, cus, d); run<17>("v_sub sgpr", 8, cus, d); run<18>("v_mul literal", 8, cus, d);
+    run<19>("v_max_f32 literal", 8, cus, d); run<20>("v_add_f32 literal", 8, cus, d); run<21>("v_mad_u32_u24", 8, cus, d); run<22>("v_add_u32", 8, cus, d); run<23>("v_lshlrev_b32", 8, cus, d); run<24>("v_mul_u32_u24", 8, cus, d); run<25>("v_and_b32", 8, cus, d); run<26>("v_add_lshl_u32", 8, cus, d); run<27>("v_med3_f32", 8, cus, d); run<28>("v_bfi_b32", 8, cus, d); run<29>("v_mul_f32 omod", 8, cus, d); run<30>("v_max_f32 vgpr", 8, cus, d); run<31>("v_mad_u64_u32?", 8, cus, d); run<32>("v_add3_u32", 8, cus, d); run<33>("v_lshl_or_b32", 8, cus, d); run<34>("v_sub_f32 vgpr", 8, cus, d); run<35>("v_mul_f32 vgpr", 8, cus, d); run<36>("v_fma_f32 neg", 8, cus, d); run<37>("v_rcp_f32", 8, cus, d); run<38>("v_exp_f32", 8, cus, d); run<39>("v_mov_b32", 8, cus, d); run<40>("v_xad_u32", 8, cus, d);
+    run<41>("v_pk_mad_u16", 8, cus, d); run<42>("v_pk_add_u16", 8, cus, d); run<43>("v_mad_u32_u16", 8, cus, d);
     for (int w : {4, 5}) { run<0>("v_fma_f32", w, cus, d); }
     return 0;
 }
