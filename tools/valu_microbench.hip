@@ -12,6 +12,7 @@
 template <int OP> __global__ void __launch_bounds__(256) k(float* out, float seed) {
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float m = 0.999f, c = 0.001f;
+    double q0 = seed, q1 = seed + 1, q2 = seed + 2, q3 = seed + 3;   // register pairs of the mixed streams
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int r = 0; r < REP / 8; ++r) {
@@ -187,6 +188,56 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, float see
                 asm volatile("v_mad_u32_u16 %0, %0, %8, %9\n v_mad_u32_u16 %1, %1, %8, %9\n v_mad_u32_u16 %2, %2, %8, %9\n v_mad_u32_u16 %3, %3, %8, %9\n"
                              "v_mad_u32_u16 %4, %4, %8, %9\n v_mad_u32_u16 %5, %5, %8, %9\n v_mad_u32_u16 %6, %6, %8, %9\n v_mad_u32_u16 %7, %7, %8, %9"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (OP == 50) {  // mix 6fma+2max
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_max_f32 %3, %3, %12\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_max_f32 %7, %7, %12"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 51) {  // mix 4fma+4max
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_max_f32 %1, %1, %12\n v_fma_f32 %2, %2, %12, %13\n v_max_f32 %3, %3, %12\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_max_f32 %5, %5, %12\n v_fma_f32 %6, %6, %12, %13\n v_max_f32 %7, %7, %12"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 52) {  // mix 6fma+2pkfma
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_pk_fma_f32 %11, %11, %14, %15\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_pk_fma_f32 %11, %11, %14, %15"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 53) {  // mix 4fma+4pkfma
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_pk_fma_f32 %9, %9, %14, %15\n v_fma_f32 %2, %2, %12, %13\n v_pk_fma_f32 %11, %11, %14, %15\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_pk_fma_f32 %9, %9, %14, %15\n v_fma_f32 %6, %6, %12, %13\n v_pk_fma_f32 %11, %11, %14, %15"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 54) {  // mix 6fma+2rsq
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_rsq_f32 %3, %3\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_rsq_f32 %7, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 55) {  // mix 7fma+1rsq
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_rsq_f32 %7, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 56) {  // mix 6fma+2lshl
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_lshl_add_u32 %3, %3, 23, %12\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_lshl_add_u32 %7, %7, 23, %12"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 57) {  // 8 pkfma (4 pairs)
+                asm volatile("v_pk_fma_f32 %8, %8, %14, %15\n v_pk_fma_f32 %9, %9, %14, %15\n v_pk_fma_f32 %10, %10, %14, %15\n v_pk_fma_f32 %11, %11, %14, %15\n"
+                             "v_pk_fma_f32 %8, %8, %14, %15\n v_pk_fma_f32 %9, %9, %14, %15\n v_pk_fma_f32 %10, %10, %14, %15\n v_pk_fma_f32 %11, %11, %14, %15"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 58) {  // mix 4fma+4pkmul
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_pk_mul_f32 %9, %9, %14\n v_fma_f32 %2, %2, %12, %13\n v_pk_mul_f32 %11, %11, %14\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_pk_mul_f32 %9, %9, %14\n v_fma_f32 %6, %6, %12, %13\n v_pk_mul_f32 %11, %11, %14"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
+            } else if (OP == 59) {  // mix 2fma+6pkfma
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n v_pk_fma_f32 %9, %9, %14, %15\n v_pk_fma_f32 %10, %10, %14, %15\n v_pk_fma_f32 %11, %11, %14, %15\n"
+                             "v_fma_f32 %4, %4, %12, %13\n v_pk_fma_f32 %9, %9, %14, %15\n v_pk_fma_f32 %10, %10, %14, %15\n v_pk_fma_f32 %11, %11, %14, %15"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                             : "v"(m), "v"(c), "v"(1.0), "v"(0.0));
             } else if (OP == 9) {  // v_fma_f64
                 asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
                              "v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5"
@@ -194,7 +245,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, float see
             }
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(q0 + q1 + q2 + q3);
 }
 
 template <int OP> void run(const char* name, int blocksPerCU, int cus, float* d) {
@@ -228,6 +279,8 @@ int main() {
     run<16>("v_fma sgpr", 8, cus, d); run<17>("v_sub sgpr", 8, cus, d); run<18>("v_mul literal", 8, cus, d);
     run<19>("v_max_f32 literal", 8, cus, d); run<20>("v_add_f32 literal", 8, cus, d); run<21>("v_mad_u32_u24", 8, cus, d); run<22>("v_add_u32", 8, cus, d); run<23>("v_lshlrev_b32", 8, cus, d); run<24>("v_mul_u32_u24", 8, cus, d); run<25>("v_and_b32", 8, cus, d); run<26>("v_add_lshl_u32", 8, cus, d); run<27>("v_med3_f32", 8, cus, d); run<28>("v_bfi_b32", 8, cus, d); run<29>("v_mul_f32 omod", 8, cus, d); run<30>("v_max_f32 vgpr", 8, cus, d); run<31>("v_mad_u64_u32?", 8, cus, d); run<32>("v_add3_u32", 8, cus, d); run<33>("v_lshl_or_b32", 8, cus, d); run<34>("v_sub_f32 vgpr", 8, cus, d); run<35>("v_mul_f32 vgpr", 8, cus, d); run<36>("v_fma_f32 neg", 8, cus, d); run<37>("v_rcp_f32", 8, cus, d); run<38>("v_exp_f32", 8, cus, d); run<39>("v_mov_b32", 8, cus, d); run<40>("v_xad_u32", 8, cus, d);
     run<41>("v_pk_mad_u16", 8, cus, d); run<42>("v_pk_add_u16", 8, cus, d); run<43>("v_mad_u32_u16", 8, cus, d);
+    run<50>("mix 6fma+2max", 8, cus, d); run<51>("mix 4fma+4max", 8, cus, d); run<52>("mix 6fma+2pkfma", 8, cus, d); run<53>("mix 4fma+4pkfma", 8, cus, d); run<54>("mix 6fma+2rsq", 8, cus, d); run<55>("mix 7fma+1rsq", 8, cus, d); run<56>("mix 6fma+2lshl", 8, cus, d); run<57>("8 pkfma (4 pairs)", 8, cus, d); run<58>("mix 4fma+4pkmul", 8, cus, d); run<59>("mix 2fma+6pkfma", 8, cus, d);
+    run<50>("mix 6fma+2max", 6, cus, d); run<51>("mix 4fma+4max", 6, cus, d); run<52>("mix 6fma+2pkfma", 6, cus, d); run<53>("mix 4fma+4pkfma", 6, cus, d); run<54>("mix 6fma+2rsq", 6, cus, d); run<55>("mix 7fma+1rsq", 6, cus, d); run<56>("mix 6fma+2lshl", 6, cus, d); run<57>("8 pkfma (4 pairs)", 6, cus, d); run<58>("mix 4fma+4pkmul", 6, cus, d); run<59>("mix 2fma+6pkfma", 6, cus, d);
     for (int w : {4, 5}) { run<0>("v_fma_f32", w, cus, d); }
     return 0;
 }
