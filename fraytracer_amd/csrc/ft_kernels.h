@@ -9,7 +9,7 @@
 #define FT_BLOCK 256          // 4 waves; every wave is an independent persistent worker
 // dynamic LDS of a trace workgroup starts with FT_LDS_STAT_ROWS rows of per-lane statistics words and 4 clock dwords
 #ifdef FT_UNION_PROFILE
-#define FT_LDS_STAT_ROWS 17   // diagnostic build: + 10 rows of union-walk counters (kernels.hip FT_UDBG)
+#define FT_LDS_STAT_ROWS 20   // diagnostic build: + 12 rows of union-walk counters (kernels.hip FT_UDBG) + 1 scratch row
 #else
 #define FT_LDS_STAT_ROWS 7
 #endif

@@ -273,7 +273,8 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 // the loop it measures: [0] loop trips summed over lanes, [1] loop trips per wave x 64, [2] candidate evaluations summed over
 // lanes, [3] candidate-evaluation blocks per wave x 64, [4] shader cycles inside the union walk (per wave), [5] inside the whole
 // scene evaluation, [6] wave-level evaluations x 64, [7] shader cycles of whole rounds (evaluation + state machine + refill)
-__device__ unsigned long long ft_union_dbg[10];   // [8] shader cycles a wave waits for the candidate records of a trip, [9] cycles in candidate evaluations
+__device__ unsigned long long ft_union_dbg[12];   // [8] shader cycles a wave waits for the candidate records of a trip, [9] cycles in candidate evaluations,
+                                                  // [10] wave-level evaluations x 64 whose active lanes share ONE lookup cell, [11] ... the same cell as the evaluation before
 __device__ __forceinline__ void ft_dbg_add(uint32_t k, uint32_t v) {
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + (7u + k) * FT_BLOCK, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -307,6 +308,15 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     cfp consts = as_const(S.consts);
     uint32_t i = cellStart[cell];
     const uint32_t end = cellStart[cell + 1];
+#ifdef FT_UNION_PROFILE
+    {
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
+        const bool uni = __ballot(cell != u) == 0ull;
+        uint32_t* prev = reinterpret_cast<uint32_t*>(ft_lds) + 19u * FT_BLOCK + (threadIdx.x & ~63u);
+        if (uni) { FT_UDBG_WAVE(10); if (*prev == u) FT_UDBG_WAVE(11); }
+        if (ft_dbg_leader()) *prev = uni ? u : 0xffffffffu;
+    }
+#endif
 
     // The reference scans the whole list (SdfForm.fs:27), testing  min > LowerBound - distanceToCenter (:30)  and
     // min > getMinDistance (:31)  before it evaluates a candidate.  The list is sorted by LowerBound (SdfBoundary.fs:267-268;
@@ -927,7 +937,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         if (blockIdx.x == 0 && tid == 0) { atomicAdd(&a.stats->clk_shader, clock64() - clk0[0]); atomicAdd(&a.stats->clk_ref, wall_clock64() - clk0[1]); }
     }
 #ifdef FT_UNION_PROFILE
-    for (uint32_t k = 0; k < 10; ++k) {
+    for (uint32_t k = 0; k < 12; ++k) {
         const unsigned long long v = wave_sum(cw[(7u + k) * FT_BLOCK]);
         if (lane == 0 && v) atomicAdd(&ft_union_dbg[k], v);
     }
@@ -1263,10 +1273,10 @@ extern "C" hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsig
     return hipGetLastError();
 }
 #ifdef FT_UNION_PROFILE
-extern "C" hipError_t ft_debug_union_counters(unsigned long long out[10]) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 10);
+extern "C" hipError_t ft_debug_union_counters(unsigned long long out[12]) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_union_dbg), sizeof(unsigned long long) * 12);
     if (e != hipSuccess) return e;
-    unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(ft_union_dbg), zero, sizeof(zero));
 }
 #endif
