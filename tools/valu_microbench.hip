@@ -9,7 +9,10 @@
 #define REP 64
 #define ITERS 16384
 
+__device__ unsigned long long g_clk[2];
 template <int OP> __global__ void __launch_bounds__(256) k(float* out, float seed) {
+    unsigned long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = clock64(); r0 = wall_clock64(); }
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float m = 0.999f, c = 0.001f;
     double q0 = seed, q1 = seed + 1, q2 = seed + 2, q3 = seed + 3;   // register pairs of the mixed streams
@@ -245,6 +248,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(float* out, float see
             }
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = clock64() - c0; g_clk[1] = wall_clock64() - r0; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(q0 + q1 + q2 + q3);
 }
 
@@ -259,8 +263,11 @@ template <int OP> void run(const char* name, int blocksPerCU, int cus, float* d)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double waveInstr = (double)blocks * 4 * ITERS * REP;         // wave-level instructions
     const double perSimdPerSec = waveInstr / (cus * 4.0) / (ms * 1e-3);
-    printf("%-14s waves/SIMD %d: %.3f ms, %.3f G wave-instr/s/SIMD -> %.2f cycles/instr @2.4GHz, chip %.1f T lane-ops/s\n", name, blocksPerCU,
-           ms, perSimdPerSec / 1e9, 2.4e9 / perSimdPerSec, waveInstr * 64 / (ms * 1e-3) / 1e12);
+    unsigned long long clk[2] = {0, 1};
+    hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk));
+    const double mhz = 100.0 * (double)clk[0] / (double)clk[1];        // s_memrealtime ticks at 100 MHz
+    printf("%-14s waves/SIMD %d: %.3f ms, %.3f G wave-instr/s/SIMD -> %.2f cycles/instr @2.4GHz, chip %.1f T lane-ops/s; shader clock %.0f MHz -> %.2f shader cycles/instr\n", name, blocksPerCU,
+           ms, perSimdPerSec / 1e9, 2.4e9 / perSimdPerSec, waveInstr * 64 / (ms * 1e-3) / 1e12, mhz, mhz * 1e6 / perSimdPerSec);
 }
 
 int main() {
