@@ -778,11 +778,14 @@ int ft_selftest_fastmath(ft_ctx* c, uint64_t mismatches[3]) {
     HIP_TRY(hipMemsetAsync(d, 0, 24, c->stream));
     // sqrt: every float in [2^-96, 2^100]; exp: every float in [-2.9e6, -0] and [+0, 88]
     HIP_TRY(ft_launch_selftest(0, 0x0F800000u, 0x71800000u, d, c->stream));
+    HIP_TRY(ft_launch_selftest(3, 0x0F800000u, 0x71800000u, d, c->stream));    // the 4-instruction form (output modifiers) under the NEAR loop's mode: same range, same counter
     HIP_TRY(ft_launch_selftest(1, 0x80000000u, 0xCA310080u, d + 1, c->stream));
     HIP_TRY(ft_launch_selftest(1, 0x00000000u, 0x42B00000u, d + 1, c->stream));
     // exponent-add form of exp ("near" regime): every float in [-87, -0] and [+0, 88]
     HIP_TRY(ft_launch_selftest(2, 0x80000000u, 0xC2AE0000u, d + 2, c->stream));
     HIP_TRY(ft_launch_selftest(2, 0x00000000u, 0x42B00000u, d + 2, c->stream));
+    HIP_TRY(ft_launch_selftest(4, 0x80000000u, 0xC2AE0000u, d + 2, c->stream));  // the same form under the NEAR loop's mode (IEEE off, f32 denormals flushed)
+    HIP_TRY(ft_launch_selftest(4, 0x00000000u, 0x42B00000u, d + 2, c->stream));
     unsigned long long h[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

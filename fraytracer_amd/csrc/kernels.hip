@@ -86,6 +86,33 @@ __device__ __forceinline__ float ft_sqrt_fast(float x) {
     return fmaf(d, h, s);                           // s + d/(2 sqrt(x)): correctly rounded on the whole proved range
 }
 
+// The same root in FOUR instructions, for code that runs with output modifiers enabled (FT_OMOD_ON / FT_OMOD_OFF below): the halving of the
+// seed and the doubling of q*h ride on the instructions' output modifiers.  h = rsq(x)/2 and s = 2 * rn(x*h) = rn(x * rsq(x)) are the values
+// ft_sqrt_fast computes (scaling by 2 commutes with rounding away from the subnormal range, and x in [2^-96, 2^100] keeps both far from it),
+// so the result is bit-identical — and proved so by exhaustion under the same mode (ft_selftest_fastmath).
+__device__ __forceinline__ float ft_sqrt_fast_omod(float x) {
+    float h, s;
+    asm("v_rsq_f32_e64 %0, %1 div:2" : "=v"(h) : "v"(x));
+    asm("v_mul_f32_e64 %0, %1, %2 mul:2" : "=v"(s) : "v"(x), "v"(h));
+    const float d = fmaf(-s, s, x);
+    return fmaf(d, h, s);
+}
+// The hardware honours output modifiers only with MODE.IEEE = 0 AND f32 denormals flushed (MODE.FP_DENORM[1:0] = 0).  FT_OMOD_ON saves
+// MODE[9:4] and clears those three bits, FT_OMOD_OFF restores the saved value.  Only the NEAR sphere loop runs in between: its operands are
+// finite (fast_point_ok), every exponential is a normal number (near_point_ok), and the values flushing could touch cannot reach a result —
+// a subnormal square or residual is below half an ulp of what it is added to or sits under the 2^-96 clamp — which the exhaustive checks
+// of the root and of the exponent-add exp confirm under this very mode.  The operands tie the switch into the data flow: everything computed
+// from p comes after FT_OMOD_ON, everything that uses the sum after FT_OMOD_OFF.
+__device__ __forceinline__ uint32_t ft_omod_on(f3& p) {
+    uint32_t saved, tmp;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_MODE, 4, 6)\n\ts_andn2_b32 %1, %0, 0x23\n\ts_setreg_b32 hwreg(HW_REG_MODE, 4, 6), %1\n\ts_nop 1"
+                 : "=&s"(saved), "=&s"(tmp), "+v"(p.x), "+v"(p.y), "+v"(p.z));
+    return saved;
+}
+__device__ __forceinline__ void ft_omod_off(uint32_t saved, float& v) {
+    asm volatile("s_setreg_b32 hwreg(HW_REG_MODE, 4, 6), %1\n\ts_nop 1" : "+v"(v) : "s"(saved));
+}
+
 template <bool FQ> __device__ __forceinline__ float ft_sq(float q) {
     return FQ ? ft_sqrt_fast(__builtin_fmaxf(q, FT_FAST_Q_MIN)) : sqrtf(q);
 }
@@ -222,11 +249,20 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 #define FT_STR(x) FT_STR2(x)
 #define FT_LOOP_PHASE() asm volatile(".p2align 6\n\t.rept " FT_STR(FT_LOOP_PAD) "\n\ts_nop 0\n\t.endr" ::: "memory")
 
+#ifndef FT_SQRT_5
+#define FT_LOOP_SQRT(q) (NEAR ? ft_sqrt_fast_omod(q) : ft_sqrt_fast(q))
+#else
+#define FT_LOOP_SQRT(q) ft_sqrt_fast(q)
+#endif
 template <bool NEAR>
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
     float si = si_;
     asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
+#ifndef FT_SQRT_5
+    uint32_t mode = 0;
+    if (NEAR) mode = ft_omod_on(p);
+#endif
     FT_LOOP_PHASE();
     for (; i + FT_UNROLL <= count; i += FT_UNROLL) {
         float4 prm[FT_UNROLL];
@@ -239,13 +275,16 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
             q[j] = __builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN);
         }
 #pragma unroll
-        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast<NEAR>(si * (ft_sqrt_fast(q[j]) - prm[j].w));
+        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast<NEAR>(si * (FT_LOOP_SQRT(q[j]) - prm[j].w));
     }
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
         const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
-        sum = sum + ft_exp_fast<NEAR>(si * (ft_sqrt_fast(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)) - prm.w));
+        sum = sum + ft_exp_fast<NEAR>(si * (FT_LOOP_SQRT(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)) - prm.w));
     }
+#ifndef FT_SQRT_5
+    if (NEAR) ft_omod_off(mode, sum);
+#endif
     return sum;
 }
 
@@ -1186,6 +1225,14 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
     for (unsigned long long u = (unsigned long long)lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= hi;
          u += (unsigned long long)gridDim.x * blockDim.x) {
         const float x = __uint_as_float((uint32_t)u);
+        if (op >= 3) {                                                 // the NEAR sphere loop's forms under its mode: 3 = four-instruction root, 4 = exponent-add exp
+            f3 y = mk3(x, x, x);
+            const uint32_t mode = ft_omod_on(y);
+            float a = op == 3 ? ft_sqrt_fast_omod(y.x) : ft_exp_fast<true>(y.x);
+            ft_omod_off(mode, a);
+            bad += __float_as_uint(a) != __float_as_uint(op == 3 ? sqrtf(x) : ft_exp(x));
+            continue;
+        }
         const float a = op == 0 ? ft_sqrt_fast(x) : (op == 1 ? ft_exp_fast<false>(x) : ft_exp_fast<true>(x));
         const float b = op == 0 ? sqrtf(x) : ft_exp(x);
         bad += __float_as_uint(a) != __float_as_uint(b);

@@ -183,11 +183,53 @@ def fix(src, dst):
     return report
 
 
+# What may stand between the two MODE writes of the NEAR sphere loop (kernels.hip ft_omod_on / ft_omod_off: IEEE off, f32 denormals flushed,
+# so that output modifiers work): the loop's own float forms, and anything that does not look at the float mode (integer, lane, LDS, scalar).
+MODE_REGION_OK = re.compile(r"v_(sub|mul|add|max|fma|fmac|fmamk|fmaak)_f32|v_rsq_f32|v_lshl_add_u32|v_mov_b32|v_readlane_b32|v_writelane_b32|"
+                            r"v_(add|sub|subrev|lshlrev|lshrrev|and|or)_[ub]32|v_add3_u32|v_add_lshl_u32|v_cmp_\w+_[ui]32|v_cndmask_b32|ds_read_b128|s_|buffer_|scratch_|global_load")
+
+
+def mode_regions(dis):
+    """[(symbol, [instruction text])] for every stretch between the MODE write that follows an s_andn2 (on) and the next MODE write (off)"""
+    out, sym, on, prev = [], None, None, ""
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([\w.$]+)>:", line)
+        if m:
+            if not m.group(1).startswith(MARK):
+                sym = m.group(1)
+            continue
+        m = re.match(r"\s+(\S.*?)\s+// [0-9A-F]+:", line)
+        if not m:
+            continue
+        text = m.group(1)
+        if text.startswith("s_setreg_b32 hwreg(HW_REG_MODE, 4, 6)"):
+            if prev.startswith("s_andn2_b32"):
+                on = []
+            elif on is not None:
+                out.append((sym, on)); on = None
+        elif on is not None:
+            on.append(text)
+        prev = text
+    if on is not None:
+        raise SystemExit(f"loop_layout: {sym}: a MODE write without its restore")
+    return out
+
+
 def check(path, only_trace_kernels=True):
     with tempfile.TemporaryDirectory() as tmp:
         co = device_code_object(path, tmp) if not path.endswith((".co", ".hsaco")) else path
         bad = n = 0
-        for sym, kind, body in sphere_loops(disassemble(co)):
+        dis = disassemble(co)
+        regions = mode_regions(dis)
+        for sym, body in regions:
+            foreign = sorted({t.split()[0] for t in body if not MODE_REGION_OK.match(t)})
+            rsq = sum(1 for t in body if t.startswith("v_rsq_f32"))
+            ok = not foreign and (rsq in (1, 5)) and len(body) < 260        # the loop (4 roots) and its remainder (1), or the self-test's single root
+            bad += not ok
+            print(f"{sym}: output-modifier region of {len(body)} instructions, {rsq} roots -> " + ("only the sphere loop inside" if ok else f"FOREIGN CODE inside: {foreign}"))
+        if not regions:
+            raise SystemExit("loop_layout: no output-modifier region found: the check needs updating")
+        for sym, kind, body in sphere_loops(dis):
             if only_trace_kernels and not sym.startswith("ft_trace_kernel"):
                 continue
             phase, run = run_phase(body)

@@ -226,8 +226,9 @@ int ft_scene_grid_dump(const ft_scene*, int32_t g, uint32_t* cell_start, float* 
  * (y = second operand, may be NULL otherwise).  Used by tests/test_math_parity.py. */
 int ft_math_eval(ft_ctx*, int32_t op, const float* x, const float* y, int64_t n, float* out);
 /* Exhaustive check, on the GPU, of the fast sqrt / exp forms used inside the smooth-union loop against
- * the exact forms, over EVERY float of the ranges they are used on; mismatches[0] = sqrt,
- * [1] = exp (ldexp form, [-2.9e6, 88]), [2] = exp (exponent-add form, [-87, 88]); all must be 0. */
+ * the exact forms, over EVERY float of the ranges they are used on; mismatches[0] = sqrt (both the five-instruction
+ * form and the four-instruction form that runs with output modifiers enabled), [1] = exp (ldexp form, [-2.9e6, 88]),
+ * [2] = exp (exponent-add form, [-87, 88], in the normal mode and under the near loop's mode); all must be 0. */
 int ft_selftest_fastmath(ft_ctx*, uint64_t mismatches[3]);
 
 #ifdef __cplusplus
