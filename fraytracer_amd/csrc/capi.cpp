@@ -778,6 +778,7 @@ int ft_selftest_fastmath(ft_ctx* c, uint64_t mismatches[3]) {
     HIP_TRY(hipMemsetAsync(d, 0, 24, c->stream));
     // sqrt: every float in [2^-96, 2^100]; exp: every float in [-2.9e6, -0] and [+0, 88]
     HIP_TRY(ft_launch_selftest(0, 0x0F800000u, 0x71800000u, d, c->stream));
+    HIP_TRY(ft_launch_selftest(5, 0x27800000u, 0x48000000u, d, c->stream));    // strength -2 / -4 / -1/2 through the subtraction's output modifier: every root in [2^-48, 2^17] x four radii
     HIP_TRY(ft_launch_selftest(3, 0x0F800000u, 0x71800000u, d, c->stream));    // the 4-instruction form (output modifiers) under the NEAR loop's mode: same range, same counter
     HIP_TRY(ft_launch_selftest(1, 0x80000000u, 0xCA310080u, d + 1, c->stream));
     HIP_TRY(ft_launch_selftest(1, 0x00000000u, 0x42B00000u, d + 1, c->stream));

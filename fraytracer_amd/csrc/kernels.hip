@@ -254,8 +254,23 @@ __device__ __forceinline__ float ft_exp_fast(float x) {
 #else
 #define FT_LOOP_SQRT(q) ft_sqrt_fast(q)
 #endif
-template <bool NEAR>
+// t = si * (s - w) for the strengths -2, -4 and -1/2 (unionSmooth 0.5, 0.25 — BASELINE.json's configs 3 and 4 — and 2): a product with a power of
+// two is exact, so t = (w - s) * 2^k, and the scaling rides on the subtraction's output modifier (PW = 1: mul:2, 2: mul:4, 3: div:2; only inside the
+// near loop's mode region).  |w - s| is 0 or at least 2^-44 and below 2^17, so nothing under- or overflows; a zero may come out as +0 where the product
+// gives -0, which ft_exp_fast maps to the same 1.0f.  PW = 0 is the general product.
+template <int PW> __device__ __forceinline__ float ft_strength_times_diff(float si, float s, float w) {
+    float t;
+    if (PW == 1) asm("v_sub_f32_e64 %0, %1, %2 mul:2" : "=v"(t) : "v"(w), "v"(s));
+    else if (PW == 2) asm("v_sub_f32_e64 %0, %1, %2 mul:4" : "=v"(t) : "v"(w), "v"(s));
+    else if (PW == 3) asm("v_sub_f32_e64 %0, %1, %2 div:2" : "=v"(t) : "v"(w), "v"(s));
+    else t = si * (s - w);
+    return t;
+}
+__device__ __forceinline__ int ft_strength_pw(float si) { return si == -2.0f ? 1 : (si == -4.0f ? 2 : (si == -0.5f ? 3 : 0)); }
+
+template <bool NEAR, int PW = 0>
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
+    static_assert(NEAR || PW == 0, "output modifiers exist only in the near loop's mode region");
     float si = si_;
     asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
@@ -275,12 +290,12 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
             q[j] = __builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN);
         }
 #pragma unroll
-        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast<NEAR>(si * (FT_LOOP_SQRT(q[j]) - prm[j].w));
+        for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast<NEAR>(ft_strength_times_diff<PW>(si, FT_LOOP_SQRT(q[j]), prm[j].w));
     }
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
         const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
-        sum = sum + ft_exp_fast<NEAR>(si * (FT_LOOP_SQRT(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)) - prm.w));
+        sum = sum + ft_exp_fast<NEAR>(ft_strength_times_diff<PW>(si, FT_LOOP_SQRT(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)), prm.w));
     }
 #ifndef FT_SQRT_5
     if (NEAR) ft_omod_off(mode, sum);
@@ -580,7 +595,16 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
         const uint32_t op = in->op;
         if (op == FT_OP_SMOOTH_RUN) {
             const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
-            if (__builtin_expect(nearOk, 1)) acc = smooth_run_spheres_fast<true>(ldsC + in->data, in->count, in->f0, p, sum0);
+            if (__builtin_expect(nearOk, 1)) {
+#ifndef FT_SQRT_5
+                const int pw = ft_strength_pw(in->f0);                 // wave-uniform: the strength is an instruction field
+                if (pw == 2) acc = smooth_run_spheres_fast<true, 2>(ldsC + in->data, in->count, in->f0, p, sum0);
+                else if (pw == 1) acc = smooth_run_spheres_fast<true, 1>(ldsC + in->data, in->count, in->f0, p, sum0);
+                else if (pw == 3) acc = smooth_run_spheres_fast<true, 3>(ldsC + in->data, in->count, in->f0, p, sum0);
+                else
+#endif
+                acc = smooth_run_spheres_fast<true>(ldsC + in->data, in->count, in->f0, p, sum0);
+            }
             else if (fastOk) acc = smooth_run_spheres_fast<false>(ldsC + in->data, in->count, in->f0, p, sum0);
             else {                                                     // exact loop (SdfForm.fs:77-80, :129)
                 acc = sum0;
@@ -1225,6 +1249,22 @@ extern "C" __global__ void ft_selftest_kernel(int op, uint32_t lo, uint32_t hi, 
     for (unsigned long long u = (unsigned long long)lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= hi;
          u += (unsigned long long)gridDim.x * blockDim.x) {
         const float x = __uint_as_float((uint32_t)u);
+        if (op == 5) {                                                 // strength * (s - w) through the subtraction's output modifier, x = s, four radii
+            const float ws[4] = {0x1p-20f, 0.1f, 1.0f, 1.0e4f};
+            for (int k = 0; k < 4; ++k) {
+                f3 y = mk3(x, ws[k], 0.0f);
+                const uint32_t mode = ft_omod_on(y);
+                float t1 = ft_strength_times_diff<1>(0.0f, y.x, y.y), t2 = ft_strength_times_diff<2>(0.0f, y.x, y.y), t3 = ft_strength_times_diff<3>(0.0f, y.x, y.y);
+                asm volatile("" : "+v"(t1), "+v"(t2), "+v"(t3));         // all three are computed before the mode is restored
+                float tie = t1;
+                ft_omod_off(mode, tie);
+                const float d = x - ws[k];
+                const float e1 = -2.0f * d, e2 = -4.0f * d, e3 = -0.5f * d;
+                bad += !(t1 == e1 && t2 == e2 && t3 == e3) || (d != 0.0f && (__float_as_uint(t1) != __float_as_uint(e1) || __float_as_uint(t2) != __float_as_uint(e2) || __float_as_uint(t3) != __float_as_uint(e3)));
+                if (tie != tie) bad += 1;
+            }
+            continue;
+        }
         if (op >= 3) {                                                 // the NEAR sphere loop's forms under its mode: 3 = four-instruction root, 4 = exponent-add exp
             f3 y = mk3(x, x, x);
             const uint32_t mode = ft_omod_on(y);

@@ -99,6 +99,23 @@ def test_c3_smooth_union_256(gpu, oracle):
     check_counts(gst, ocnt)
 
 
+@pytest.mark.parametrize("strength", [0.25, 0.5, 2.0, 0.3, 0.125])
+def test_smooth_union_strength_variants_of_the_near_loop(gpu, oracle, strength):
+    """-1/strength = -4, -2, -1/2 take the near loop whose product with the strength rides on the subtraction's output modifier
+    (kernels.hip ft_strength_times_diff); 0.3 and 0.125 (-8: no modifier for it) take the general product — all against the oracle,
+    on the lean kernel and with 4 samples per pixel on its EXTENSION build"""
+    scene, _ = syn.config3(n=67, strength=strength)             # 67 = 16 trips of four and a remainder of three
+    g, gst, o, ocnt = render_both(gpu, oracle, scene, 96, 96)
+    assert_bit_equal(g, o, f"unionSmooth {strength}")
+    check_counts(gst, ocnt)
+    cam = syn.default_camera()
+    ds, os_ = both(gpu, oracle, scene)
+    assert ds.info()["fast_path"] == 1
+    g4, _ = ds.render(EPS, LEN, ft.ImageSize(48, 48), cam, spp=4)
+    o4, _ = os_.render(EPS, LEN, 48, 48, cam.as_array(), spp=4)
+    assert_bit_equal(g4, o4, f"unionSmooth {strength}, 4 spp")
+
+
 def test_console_like_scene(gpu, oracle):
     scene, _ = syn.console_like(n=300)
     g, gst, o, ocnt = render_both(gpu, oracle, scene, 160, 160)
