@@ -282,7 +282,10 @@ def fuzz_scene(seed, big=False):
     top = pick(4)
     if big: root = SdfObject.union([SdfObject.create(material(), prim(5.0)) if pick(8) else obj(1) for _ in range(60 + pick(341))])
     elif top == 0: root = obj(1)
-    elif top == 1: root = SdfObject.create(material(), SdfForm.unionSmooth(rng.range(0.1, 0.5), [P.sphere(rng.pointInBall(3.0), rng.range(0.2, 0.8)) for _ in range(3 + pick(40))]))
+    elif top == 1:
+        strength = rng.range(0.1, 0.5)
+        if seed % 2 == 0: strength = (0.25, 0.5, 2.0, 0.125)[(seed // 2) % 4]     # -1/strength a power of two: the near loop's output-modifier variants (no extra draw: odd seeds keep their scenes)
+        root = SdfObject.create(material(), SdfForm.unionSmooth(strength, [P.sphere(rng.pointInBall(3.0), rng.range(0.2, 0.8)) for _ in range(3 + pick(40))]))
     else: root = SdfObject.union([obj(2) for _ in range(2 + pick(14))])
     lights = []
     for _ in range(pick(4)):
