@@ -409,6 +409,10 @@ int ft_scene_create(ft_ctx* c, ft_handle object, const float bg[3], const ft_han
     s->ctx = c;
     std::string err;
     if (!ft::flatten(c->builder, object, bg, lights, n, s->flat, err)) { delete s; return setErr(FT_ERR_UNSUPPORTED, err); }
+    // the union walk addresses candidate records and the constant pool with 32-bit byte offsets (kernels.hip ld_item_at / pool_at)
+    if (s->flat.items.size() >= (1ull << 27) || s->flat.consts.size() >= (1ull << 30)) {
+        delete s; return setErr(FT_ERR_UNSUPPORTED, "scene has 2^27 or more (cell, candidate) records or 2^30 or more constants");
+    }
     int rc = uploadScene(c, s);
     if (rc) { delete s; return rc; }
     *out = s;

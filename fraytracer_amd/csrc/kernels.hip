@@ -47,6 +47,15 @@ __device__ __forceinline__ ItemRegs ld_item(const FtItemRec FT_CONST* q) {
     r.b = *reinterpret_cast<const v4u FT_CONST*>(reinterpret_cast<const float FT_CONST*>(q) + 4);
     return r;
 }
+// record `idx` of a list that starts at the uniform pointer `base`: a 32-bit byte offset (lists stay far below 2^27 records: capi.cpp checks)
+// lets the load take the scalar base + 32-bit vector offset form instead of a 64-bit address built per record
+__device__ __forceinline__ ItemRegs ld_item_at(const FtItemRec FT_CONST* base, uint32_t idx) {
+    return ld_item(reinterpret_cast<const FtItemRec FT_CONST*>(reinterpret_cast<const char FT_CONST*>(base) + (size_t)(uint32_t)(idx << 5)));
+}
+// float `idx` of the constant pool, addressed the same way (the pool stays below 2^30 floats)
+__device__ __forceinline__ const float FT_CONST* pool_at(const float FT_CONST* base, uint32_t idx) {
+    return reinterpret_cast<const float FT_CONST*>(reinterpret_cast<const char FT_CONST*>(base) + (size_t)(uint32_t)(idx << 2));
+}
 __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
     FtLight r; r.type = q->type; r.v[0] = q->v[0]; r.v[1] = q->v[1]; r.v[2] = q->v[2];
     r.color[0] = q->color[0]; r.color[1] = q->color[1]; r.color[2] = q->color[2]; r.pad = 0.0f; return r;
@@ -388,7 +397,7 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     while (i < end) {
         const uint32_t j = i + 1u < end ? i + 1u : i;
         FT_UDBG_T0(tLoad);
-        const ItemRegs ra = ld_item(items + i), rb = ld_item(items + j);
+        const ItemRegs ra = ld_item_at(items, i), rb = ld_item_at(items, j);
 #ifdef FT_UNION_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -411,7 +420,7 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
         const uint32_t type = typeData & 15u, data = typeData >> 4;
         float d; uint32_t l;
         if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
-        else { d = prim_eval_t<FQ>(type, consts + data, p); l = mat; }
+        else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p); l = mat; }
         FT_UDBG_T1(9, tPrim);
         if (first) { mn = d; leaf = l; first = false; }
         else {
@@ -455,7 +464,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
     float mn = 0.0f; uint32_t leaf = 0;
     bool first = true;
     for (; i < end; ++i) {
-        const ItemRegs cur = ld_item(items + i);
+        const ItemRegs cur = ld_item_at(items, i);
         if (!first) {
             FT_UDBG(0, 1); FT_UDBG_WAVE(1);
             if (!(mn > cur.a.x - distanceToCenter)) break;             // :30 false for this and all later candidates
@@ -482,7 +491,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
                 }
             }
         }
-        else { d = prim_eval_t<FQ>(type, consts + data, p); l = cur.b.z; }
+        else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p); l = cur.b.z; }
         if (first) { mn = d; leaf = l; first = false; }
         else {
             if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
