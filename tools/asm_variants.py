@@ -26,15 +26,22 @@ def base_asm():
     return open(s).read().splitlines()
 
 
-def find_loop(lines):
-    """(index of the '.rept' line, first and last instruction line of the near loop) in ft_trace_kernel_smooth_spheres"""
+def find_loop(lines, want=os.environ.get("FT_ASM_LOOP", "mul:4")):
+    """(index of the '.rept' line, first and last instruction line) of the near loop of ft_trace_kernel_smooth_spheres whose body
+    contains `want` (default: the strength -4 variant, the one C3 runs; FT_ASM_LOOP=v_mul_f32_e32 picks a general-strength loop)"""
     f0 = next(i for i, l in enumerate(lines) if l.startswith("ft_trace_kernel_smooth_spheres:"))
-    rept = next(i for i in range(f0, len(lines)) if lines[i].strip().startswith(".rept"))
-    head = next(i for i in range(rept, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[i]) and "Inner Loop Header" in lines[i + 2])
-    label = lines[head].split(":")[0]
-    first = next(i for i in range(head, len(lines)) if lines[i].startswith("\t") and not lines[i].strip().startswith(";"))
-    last = next(i for i in range(first, len(lines)) if lines[i].strip().startswith("s_cbranch") and label in lines[i])
-    return rept, first, last
+    f1 = next(i for i in range(f0 + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    for rept in (i for i in range(f0, f1) if lines[i].strip().startswith(".rept")):
+        head = next((i for i in range(rept, f1) if re.match(r"\.LBB\d+_\d+:", lines[i]) and "Inner Loop Header" in lines[i + 2]), None)
+        if head is None:
+            continue
+        label = lines[head].split(":")[0]
+        first = next(i for i in range(head, f1) if lines[i].startswith("\t") and not lines[i].strip().startswith(";"))
+        last = next(i for i in range(first, f1) if lines[i].strip().startswith("s_cbranch") and label in lines[i])
+        body = "\n".join(lines[first:last + 1])
+        if want in body and "v_lshl_add_u32" in body:
+            return rept, first, last
+    raise SystemExit(f"no near loop containing '{want}' in ft_trace_kernel_smooth_spheres")
 
 
 def is_instr(l):
