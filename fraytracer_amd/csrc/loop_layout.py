@@ -232,7 +232,7 @@ def check(path, only_trace_kernels=True):
             bad += not ok
             print(f"{sym}: output-modifier region of {len(body)} instructions, {rsq} roots -> " + ("only the sphere loop inside" if ok else f"FOREIGN CODE inside: {foreign}"))
         if not regions:
-            raise SystemExit("loop_layout: no output-modifier region found: the check needs updating")
+            print("no output-modifier region in this build (-DFT_SQRT_5?)")       # tests/test_build_layout.py insists on them for the product library
         for sym, kind, body in sphere_loops(dis):
             if only_trace_kernels and not sym.startswith("ft_trace_kernel"):
                 continue
