@@ -351,7 +351,8 @@ def main():
                          "shader_Gcycles_per_launch": round(launch_s * st["shader_mhz"] * 1e6 / 1e9, 4),
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
                                  "flop each although a correctly rounded sqrt / reproducible exp need 4 / 11 instructions: 26 VALU instructions "
-                                 "per child against 13 algorithmic flops, issued at 2.37 cycles each at this occupancy "
+                                 "per child against 13 algorithmic flops (the near loop's root and strength product use output modifiers inside a "
+                                 "verified MODE region, DESIGN.md section 4), issued at 2.37 cycles each at this occupancy "
                                  "(DESIGN.md section 5: at the instruction-issue floor of this mix). peak is priced at 2.4 GHz; the chip "
                                  "sustains shader_mhz under this load (power management), which is the box-to-box spread. "
                                  "HBM traffic = 12 B/pixel output."},
