@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FRAYTRACER_HIP_LIB: diagnostic builds only (tools/union_divergence.py); the product is the in-tree library
 LIB_PATH = os.environ.get("FRAYTRACER_HIP_LIB") or os.path.join(_HERE, "libfraytracer_hip.so")
 
+FT_OPT_REFILL_MIN, FT_OPT_MAX_BLOCKS_PER_CU, FT_OPT_HOST_CHUNKS, FT_OPT_HOST_PIN = 1, 2, 3, 4
 FT_OK, FT_ERR_INVALID, FT_ERR_NO_DEVICE, FT_ERR_HIP, FT_ERR_UNSUPPORTED, FT_ERR_EMPTY, FT_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 
 
@@ -93,6 +94,9 @@ SYMBOLS = {
     "ft_ctx_destroy": (None, [_P]),
     "ft_last_error": (C.c_char_p, []),
     "ft_ctx_set_stream": (C.c_int, [_P, _P]),
+    "ft_build_info": (C.c_char_p, []),
+    "ft_ctx_set_option": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "ft_ctx_get_option": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32)]),
     "ft_form_sphere": (_H, [_P, C.POINTER(Sphere)]),
     "ft_form_capsule": (_H, [_P, C.POINTER(Capsule)]),
     "ft_form_torus": (_H, [_P, C.POINTER(Torus)]),
@@ -154,6 +158,20 @@ def load():
 
 
 lib = load()
+
+
+def build_info():
+    """{'src': hash of the sources the loaded library was built from, 'kind': product | profile | experiment}"""
+    return dict(kv.split("=", 1) for kv in lib.ft_build_info().decode().split(";"))
+
+
+def source_hash():
+    """the same hash computed from the source tree next to this package (csrc/source_hash.py)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ft_source_hash", os.path.join(_HERE, "csrc", "source_hash.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.source_hash()
 
 
 def last_error():

@@ -354,6 +354,18 @@ class Device:
     def set_stream(self, hip_stream):
         check(lib.ft_ctx_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
+    OPTIONS = {"refill_min": _lib.FT_OPT_REFILL_MIN, "max_blocks_per_cu": _lib.FT_OPT_MAX_BLOCKS_PER_CU,
+               "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN}
+
+    def set_option(self, name, value):
+        """ft_ctx_set_option: per-context switches (the library reads no environment variables)"""
+        check(lib.ft_ctx_set_option(self._ctx, self.OPTIONS[name], int(value)))
+
+    def get_option(self, name):
+        v = C.c_int32()
+        check(lib.ft_ctx_get_option(self._ctx, self.OPTIONS[name], C.byref(v)))
+        return int(v.value)
+
     # constructor twins ---------------------------------------------------------------------------
     def sphere(self, c, r): return check(lib.ft_form_sphere(self._ctx, C.byref(_lib.Sphere(_vec(c), r))))
     def capsule(self, a, b, r): return check(lib.ft_form_capsule(self._ctx, C.byref(_lib.Capsule(_vec(a), _vec(b), r))))

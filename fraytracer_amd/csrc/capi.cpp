@@ -9,8 +9,13 @@
 #include <vector>
 
 #include "../../include/fraytracer_hip.h"
+#include "build_hash.h"      // FT_SOURCE_HASH: written by the Makefile (source_hash.py)
 #include "ft_kernels.h"
 #include "scene.hpp"
+
+#ifndef FT_BUILD_KIND
+#define FT_BUILD_KIND "product"
+#endif
 
 namespace {
 
@@ -45,6 +50,11 @@ struct ft_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per kernel launch since last collect (at most FT_MAX_PENDING_EVENTS)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;
     double foldedMs = 0.0;                                 // kernel time of launches whose event pair was already recycled
+    // ft_ctx_set_option (experiments / A-B runs; every setting renders the same bits)
+    int optRefillMin = 64;                                 // idle lanes a wave waits for before it takes new rays (kernels.hip "Burst refill")
+    int optMaxBlocksPerCU = 0;                             // 0: the occupancy limit
+    int optHostChunks = 0;                                 // 0: automatic (4 for frames >= 16 MB)
+    int optHostPin = 1;                                    // page-lock an unregistered ft_render destination for the call
 };
 
 struct ft_scene {
@@ -216,7 +226,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     int perCU = 0;
     HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, ldsBytes(s), &perCU));
     perCU = std::max(1, std::min(perCU, 8));
-    if (const char* cap = getenv("FT_MAX_BLOCKS_PER_CU")) { const int v = atoi(cap); if (v > 0) perCU = std::min(perCU, v); }   // experiments only
+    if (c->optMaxBlocksPerCU > 0) perCU = std::min(perCU, c->optMaxBlocksPerCU);       // FT_OPT_MAX_BLOCKS_PER_CU (experiments only)
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
@@ -228,8 +238,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     // 15.8 / 12.1, at 1000^2 2.98 / 2.72 / 2.24, C2 4096^2 4.90 / 4.40 / 3.84, 300 on-demand combinators 24.6 / 14.8 / 10.3,
     // glass config 39.1 / 31.5 / 27.3, and even the VALU-bound C3 kernel 61.0 / 66.5 / 60.3: rays that start together stay in
     // step (march, the four normal probes, shadow rays), so a wave's lanes share lookup cells, list positions and branches.
-    a.refillMin = 64u;
-    if (const char* e = getenv("FT_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.refillMin = (uint32_t)v; }   // experiments
+    a.refillMin = (uint32_t)c->optRefillMin;               // 64 unless FT_OPT_REFILL_MIN says otherwise (experiments)
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
@@ -271,6 +280,28 @@ extern "C" {
 
 int ft_abi_version(void) { return FT_ABI_VERSION; }
 const char* ft_last_error(void) { return g_err.c_str(); }
+const char* ft_build_info(void) { return "src=" FT_SOURCE_HASH ";kind=" FT_BUILD_KIND; }
+
+int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
+    if (!c) return setErr(FT_ERR_INVALID, "null context");
+    switch (option) {
+    case FT_OPT_REFILL_MIN: if (value < 1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_REFILL_MIN: 1 .. 64"); c->optRefillMin = value; return FT_OK;
+    case FT_OPT_MAX_BLOCKS_PER_CU: if (value < 0 || value > 8) return setErr(FT_ERR_INVALID, "FT_OPT_MAX_BLOCKS_PER_CU: 0 (no cap) .. 8"); c->optMaxBlocksPerCU = value; return FT_OK;
+    case FT_OPT_HOST_CHUNKS: if (value < 0 || value > 16) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_CHUNKS: 0 (automatic) .. 16"); c->optHostChunks = value; return FT_OK;
+    case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
+    default: return setErr(FT_ERR_INVALID, "unknown option");
+    }
+}
+int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
+    if (!c || !value) return setErr(FT_ERR_INVALID, "null argument");
+    switch (option) {
+    case FT_OPT_REFILL_MIN: *value = c->optRefillMin; return FT_OK;
+    case FT_OPT_MAX_BLOCKS_PER_CU: *value = c->optMaxBlocksPerCU; return FT_OK;
+    case FT_OPT_HOST_CHUNKS: *value = c->optHostChunks; return FT_OK;
+    case FT_OPT_HOST_PIN: *value = c->optHostPin; return FT_OK;
+    default: return setErr(FT_ERR_INVALID, "unknown option");
+    }
+}
 
 int ft_ctx_create(int device, ft_ctx** out) {
     if (!out) return setErr(FT_ERR_INVALID, "null out pointer");
@@ -292,7 +323,8 @@ int ft_ctx_create(int device, ft_ctx** out) {
         c->ownStream = true;
         if ((e = hipMalloc((void**)&c->dCounter, 256)) != hipSuccess) { c->dCounter = nullptr; return fail(hipFail(e, "hipMalloc")); }
         if ((e = hipMalloc((void**)&c->dStats, sizeof(FtStatsDev))) != hipSuccess) { c->dStats = nullptr; return fail(hipFail(e, "hipMalloc")); }
-        if ((e = hipMemset(c->dStats, 0, sizeof(FtStatsDev))) != hipSuccess) return fail(hipFail(e, "hipMemset"));
+        if ((e = hipMemsetAsync(c->dStats, 0, sizeof(FtStatsDev), c->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail(hipFail(e, "hipMemset"));
         c->hasDevice = true;
         c->filler = new DeviceGridFiller(c);
         c->builder.gridFiller = c->filler;
@@ -501,9 +533,13 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
         c->eventPool.push_back(p);
     }
     c->events.clear();
+    // Read and reset ON THE CONTEXT'S STREAM.  The stream is hipStreamNonBlocking, i.e. it does not synchronise with the legacy
+    // null stream, and hipMemset of device memory returns before the fill has run: round 2 reset the block with a null-stream
+    // hipMemset, which could still be pending when the next launch on c->stream began adding to it.
     FtStatsDev h{};
-    HIP_TRY(hipMemcpy(&h, c->dStats, sizeof(h), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(c->dStats, 0, sizeof(FtStatsDev)));
+    HIP_TRY(hipMemcpyAsync(&h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dStats, 0, sizeof(FtStatsDev), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (st) {
         st->rays_primary = h.rays_primary; st->rays_shadow = h.rays_shadow; st->rays_ext = h.rays_ext;
         st->hits_primary = h.hits_primary; st->hits_shadow = h.hits_shadow; st->sdf_evals = h.sdf_evals;
@@ -579,7 +615,7 @@ int launchChunks(ft_ctx* c, const ft_scene* s, const ft_camera* cam, const ft_re
     if ((rc = ensureScratch(c, plan.bytes))) return rc;
     // chunks: only the reference's sampling (spp = 1: no shared sample planes) of a contiguous column range that is worth it
     plan.n = (p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 256 && plan.bytes >= ((size_t)16 << 20)) ? 4 : 1;
-    if (const char* e = getenv("FT_HOST_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 16 && p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 8 * v) plan.n = v; }   // experiments
+    if (const int v = c->optHostChunks; v >= 1 && p->spp == 1 && p->stripe_ranks == 1 && p->n_columns >= 8 * v) plan.n = v;   // FT_OPT_HOST_CHUNKS
     if ((rc = ensurePipeline(c, (size_t)plan.n + 2))) return rc;
     HIP_TRY(hipEventRecord(c->syncEvents[0], c->stream));      // whatever the caller queued on the context's stream comes first
     HIP_TRY(hipStreamWaitEvent(c->lane1, c->syncEvents[0], 0));
@@ -605,7 +641,7 @@ void drainPipeline(ft_ctx* c) {
 
 // page-lock `p` unless it already is; true if this call pinned it (the caller unpins)
 bool pinForCall(ft_ctx* c, void* p, size_t bytes) {
-    if (bytes < ((size_t)1 << 20) || getenv("FT_HOST_NO_PIN") || isPageLocked(c, p, bytes)) return false;
+    if (bytes < ((size_t)1 << 20) || !c->optHostPin || isPageLocked(c, p, bytes)) return false;
     if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) return true;
     (void)hipGetLastError();                                   // not fatal: the runtime's pageable path still works
     return false;

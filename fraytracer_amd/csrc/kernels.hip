@@ -1093,18 +1093,30 @@ extern "C" __global__ void ft_resolve_kernel(const float* __restrict__ planes, f
 // (max pass, map pass; the second read mostly hits the L2 / MALL for frames up to a few hundred MB), 3 B/pixel
 // written; the frame leaves the GPU as 3 bytes per pixel instead of 12.
 // ------------------------------------------------------------------------------------------------
-// pass 1: max over all channels of max(0.01, c) (Image.fs:40-43; every candidate is >= 0.01 > 0, so unsigned
-// integer comparison of the bit patterns orders them; NaN channels are ignored like v_max_f32 does)
+// pass 1: Image.fs:40-43, max = Max(0.01, max over pixels of getMaxColor).  getMaxColor is Max(Z, Max(Y, X)) with MathF.Max, which
+// propagates NaN (Math.fs:83), and Seq.max / Array.max (Array2D.fs:45-50) keep `acc` unless `curr > acc`: a pixel with a NaN channel
+// is skipped WHOLE — also when another of its channels would have been the global maximum.  (In the reference that holds for a
+// NaN pixel anywhere but at the head of a column or of the frame, where NaN sticks to `acc` instead; and any NaN channel then makes
+// Color.FromArgb throw in FColor.toColor.  Oracle and kernel take the position-independent rule)
+// Every candidate is >= 0.01 > 0, so unsigned integer comparison of the bit patterns orders them.
+__device__ __forceinline__ float tonemap_pixel_max(float m, float x, float y, float z) {
+    const bool nan = x != x || y != y || z != z;
+    const float pm = __builtin_fmaxf(z, __builtin_fmaxf(y, x));
+    return nan ? m : __builtin_fmaxf(m, pm);
+}
 extern "C" __global__ void __launch_bounds__(256) ft_tonemap_max_kernel(const float* __restrict__ frame, unsigned long long nFloats, uint32_t* __restrict__ maxBits) {
     float m = 0.01f;
-    const unsigned long long n4 = nFloats / 4ull;
+    const unsigned long long nPix = nFloats / 3ull, n4 = nPix / 4ull;          // groups of 4 pixels = 3 float4 (the frame is 16-byte aligned)
     const float4* f4 = reinterpret_cast<const float4*>(frame);
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const float4 v = f4[i];
-        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(v.x, v.y), __builtin_fmaxf(v.z, v.w)));
+        const float4 a = f4[3ull * i], b = f4[3ull * i + 1ull], c = f4[3ull * i + 2ull];
+        m = tonemap_pixel_max(m, a.x, a.y, a.z);
+        m = tonemap_pixel_max(m, a.w, b.x, b.y);
+        m = tonemap_pixel_max(m, b.z, b.w, c.x);
+        m = tonemap_pixel_max(m, c.y, c.z, c.w);
     }
-    for (unsigned long long i = n4 * 4ull + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nFloats; i += (unsigned long long)gridDim.x * blockDim.x)
-        m = __builtin_fmaxf(m, frame[i]);
+    for (unsigned long long i = n4 * 4ull + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nPix; i += (unsigned long long)gridDim.x * blockDim.x)
+        m = tonemap_pixel_max(m, frame[3ull * i], frame[3ull * i + 1ull], frame[3ull * i + 2ull]);
     for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_down(m, off, 64));
     __shared__ float part[4];
     if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
@@ -1352,7 +1364,7 @@ extern "C" hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t
     hipError_t e = hipMemsetAsync(maxBits, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     const unsigned maxBlocks = numCUs * 8u;
-    const unsigned long long want = (nFloats / 4ull + 255ull) / 256ull;
+    const unsigned long long want = (nFloats / 12ull + 255ull) / 256ull;      // one thread per 4 pixels
     hipLaunchKernelGGL(ft_tonemap_max_kernel, dim3((unsigned)(want < 1 ? 1 : (want < maxBlocks ? want : maxBlocks))), dim3(256), 0, st, frame, nFloats, maxBits);
     if (bmpOrder) {
         const unsigned tiles = ((X + FT_TM_TILE - 1) / FT_TM_TILE) * ((Y + FT_TM_TILE - 1) / FT_TM_TILE);

@@ -107,6 +107,7 @@ bool getComms(const std::vector<int>& devs, std::vector<ncclComm_t>& out, std::s
     g_cache = CommCache{};
     std::vector<ncclComm_t> comms(devs.size());
     ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    // a failed initialisation leaves nothing cached (g_cache was cleared above), so a later call starts from scratch
     if (r != ncclSuccess) { err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); return false; }
     g_cache.devices = devs; g_cache.comms = comms;
     out = comms;
@@ -120,14 +121,15 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
     if (!ctxs || !scenes || n <= 0 || !cam || !full || !out) return fail(FT_ERR_INVALID, "bad argument");
     const int W = full->width, H = full->height;
     if (W <= 0 || H <= 0) return fail(FT_ERR_INVALID, "empty image");
+    if (full->stripe_width < 0) return fail(FT_ERR_INVALID, "negative stripe_width");
     const int S = full->stripe_width > 0 ? full->stripe_width : W / n;
     if (S <= 0 || W % (S * n) != 0) return fail(FT_ERR_UNSUPPORTED, "width must be a multiple of stripe_width * n_devices");
     const int cols = W / n;                                   // columns per device
     const size_t slab = (size_t)cols * H * 3;                 // floats per device
 
     std::vector<int> devs(n);
+    for (int r = 0; r < n; ++r) if (!ctxs[r] || !scenes[r]) return fail(FT_ERR_INVALID, "null context / scene");
     for (int r = 0; r < n; ++r) {
-        if (!ctxs[r] || !scenes[r]) return fail(FT_ERR_INVALID, "null context / scene");
         devs[r] = ft_ctx_device_(ctxs[r]);
         if (devs[r] < 0) return fail(FT_ERR_NO_DEVICE, "context has no GPU: libfraytracer_hip has no CPU fallback");
     }
@@ -148,6 +150,8 @@ extern "C" int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scene
     std::vector<ft_stats> sts(n);
 
     auto worker = [&](int r) {
+        // RCCL's one-thread-per-device mode wants the calling thread ON the communicator's device; the HIP device is per thread
+        if (hipSetDevice(devs[r]) != hipSuccess) { rcs[r] = FT_ERR_HIP; errs[r] = "hipSetDevice failed in a device thread"; return; }
         ft_render_params p = *full;
         p.x0 = 0; p.n_columns = cols; p.stripe_width = S; p.stripe_ranks = n; p.stripe_rank = r;
         int rc = ft_render_device(ctxs[r], scenes[r], cam, &p, send[r]);

@@ -4,7 +4,7 @@
 // type: every scene value is paired with the handle of its native twin (`Gpu*` records), built by
 // constructors that have the reference's names, argument order and error behaviour, so a scene script
 // switches from `SdfForm.` / `SdfObject.` / `SdfLight.` to `Hip.SdfForm.` / ... and from
-// `scene |> SdfScene.trace |> Image.render eps len size camera` to `Hip.Image.renderScene eps len size camera scene`.
+// `scene |> FrayTracer.SdfScene.trace |> FrayTracer.Image.render eps len size camera` to `Hip.Image.renderScene eps len size camera scene`.
 // The closures stay available (`.Form`, `.Object`, `.Light`) as the CPU path.
 //
 // NOT COMPILED IN THIS REPOSITORY'S BUILD IMAGE (no .NET toolchain there); the same C ABI calls are
@@ -39,8 +39,8 @@ type FtCamera =
     static member ofCamera (c : Camera) : FtCamera =
         { Position = c.Position; Forward = c.Forward; UpScaled = c.UpScaled; RightScaled = c.RightScaled }
 
-/// ft_tonemap_params (16 B): Image.toColors' gamma; Dither = 0 -> no noise (u = 0.5), 1 -> counter-based hash of (x, y, channel, Seed);
-/// BmpOrder = 1 -> the scan0 buffer Image.toBitmap builds (Image.fs:61-86) instead of Color[X,Y] as R,G,B bytes
+/// ft_tonemap_params (16 B): FrayTracer.Image.toColors' gamma; Dither = 0 -> no noise (u = 0.5), 1 -> counter-based hash of (x, y, channel, Seed);
+/// BmpOrder = 1 -> the scan0 buffer FrayTracer.Image.toBitmap builds (Image.fs:61-86) instead of Color[X,Y] as R,G,B bytes
 [<Struct; StructLayout(LayoutKind.Sequential)>]
 type FtTonemapParams = { Gamma : float32; Dither : int; Seed : uint32; BmpOrder : int }
 
@@ -56,17 +56,25 @@ module Native =
     [<Literal>]
     let Lib = "fraytracer_hip"
 
+    /// FT_ABI_VERSION this file was written against (include/fraytracer_hip.h); checked when the context is created
+    [<Literal>]
+    let AbiVersion = 4
+
+    [<DllImport(Lib)>] extern int ft_abi_version()
+    [<DllImport(Lib)>] extern nativeint ft_build_info()
     [<DllImport(Lib)>] extern int ft_ctx_create(int device, nativeint& ctx)
+    // per-context switches (ft_option: 1 refill_min, 2 max_blocks_per_cu, 3 host_chunks, 4 host_pin, 5 tail_mode, 6 math); the library reads no environment
+    [<DllImport(Lib)>] extern int ft_ctx_set_option(nativeint ctx, int option, int value)
     [<DllImport(Lib)>] extern void ft_ctx_destroy(nativeint ctx)
     [<DllImport(Lib)>] extern nativeint ft_last_error()
     // By-reference parameters are [<Struct>] types only.  The reference's primitive records (SdfForm.fs:118-212), Ray and
     // SdfBoundary (Types.fs:9-24) are [<Struct>] records of float32 / Vector3 fields: sequential, blittable.  Vector3 is a
     // blittable BCL struct.  Camera, Lens, Camera.LookAt, SdfForm, SdfMaterial, SdfObject, SdfScene are reference records
     // and are never passed: Camera goes through FtCamera, the others through integer handles.
-    [<DllImport(Lib)>] extern int ft_form_sphere(nativeint ctx, SdfForm.Primitive.Sphere& data)
-    [<DllImport(Lib)>] extern int ft_form_capsule(nativeint ctx, SdfForm.Primitive.Capsule& data)
-    [<DllImport(Lib)>] extern int ft_form_torus(nativeint ctx, SdfForm.Primitive.Torus& data)
-    [<DllImport(Lib)>] extern int ft_form_triangle(nativeint ctx, SdfForm.Primitive.Triangle& data)
+    [<DllImport(Lib)>] extern int ft_form_sphere(nativeint ctx, FrayTracer.SdfForm.Primitive.Sphere& data)
+    [<DllImport(Lib)>] extern int ft_form_capsule(nativeint ctx, FrayTracer.SdfForm.Primitive.Capsule& data)
+    [<DllImport(Lib)>] extern int ft_form_torus(nativeint ctx, FrayTracer.SdfForm.Primitive.Torus& data)
+    [<DllImport(Lib)>] extern int ft_form_triangle(nativeint ctx, FrayTracer.SdfForm.Primitive.Triangle& data)
     [<DllImport(Lib)>] extern int ft_form_union(nativeint ctx, int[] forms, int n)
     [<DllImport(Lib)>] extern int ft_form_subtract(nativeint ctx, int a, int b)
     [<DllImport(Lib)>] extern int ft_form_intersect(nativeint ctx, int[] forms, int n)
@@ -87,15 +95,20 @@ module Native =
     // a destination that is reused over many frames can be page-locked once (otherwise ft_render pins it for the duration of each call)
     [<DllImport(Lib)>] extern int ft_host_register(nativeint ctx, nativeint p, uint64 bytes)
     [<DllImport(Lib)>] extern int ft_host_unregister(nativeint ctx, nativeint p)
-    // Image.toColors on the GPU: host FColor[,] in, bytes out / render + tone map in one call (only 3 bytes per pixel cross PCIe)
+    // FrayTracer.Image.toColors on the GPU: host FColor[,] in, bytes out / render + tone map in one call (only 3 bytes per pixel cross PCIe)
     [<DllImport(Lib)>] extern int ft_tone_map_host(nativeint ctx, nativeint frame, int X, int Y, FtTonemapParams& p, nativeint out, float32& maxOut)
     [<DllImport(Lib)>] extern int ft_render_colors(nativeint ctx, nativeint scene, FtCamera& camera, FtRenderParams& p, FtTonemapParams& tm, nativeint out, float32& maxOut, FtStats& stats)
 
     /// one context for the process (GPU 0); there is no CPU fallback inside the library
     let ctx =
-        lazy (let mutable c = 0n
+        lazy (if ft_abi_version () <> AbiVersion then failwithf "libfraytracer_hip has ABI %d, this binding was written for %d" (ft_abi_version ()) AbiVersion
+              let mutable c = 0n
               if ft_ctx_create (0, &c) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))
               c)
+
+    /// FT_OPT_MATH (6): 0 = the library's fixed exp / log / pow (same bits on every machine), 1 = glibc's expf / logf / powf restated
+    /// on the GPU — what MathF.Exp / Log / Pow return under .NET on Linux x64, i.e. the CPU path of this very process
+    let setMath (mode : int) = if ft_ctx_set_option (ctx.Value, 6, mode) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))
 
     let check (h : int) =
         if h < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ())) else h
@@ -112,36 +125,36 @@ module SdfForm =
     let private nodes (forms : GpuForm[]) = forms |> Array.map (fun f -> f.Node)
 
     module Primitive =
-        let sphere (data : SdfForm.Primitive.Sphere) =                                           // SdfForm.fs:125-135
+        let sphere (data : FrayTracer.SdfForm.Primitive.Sphere) =                                           // SdfForm.fs:125-135
             let mutable d = data
-            { Form = SdfForm.Primitive.sphere data; Node = Native.check (Native.ft_form_sphere (Native.ctx.Value, &d)) }
-        let capsule (data : SdfForm.Primitive.Capsule) =                                         // SdfForm.fs:145-170
+            { Form = FrayTracer.SdfForm.Primitive.sphere data; Node = Native.check (Native.ft_form_sphere (Native.ctx.Value, &d)) }
+        let capsule (data : FrayTracer.SdfForm.Primitive.Capsule) =                                         // SdfForm.fs:145-170
             let mutable d = data
-            { Form = SdfForm.Primitive.capsule data; Node = Native.check (Native.ft_form_capsule (Native.ctx.Value, &d)) }
-        let torus (data : SdfForm.Primitive.Torus) =                                             // SdfForm.fs:181-203
+            { Form = FrayTracer.SdfForm.Primitive.capsule data; Node = Native.check (Native.ft_form_capsule (Native.ctx.Value, &d)) }
+        let torus (data : FrayTracer.SdfForm.Primitive.Torus) =                                             // SdfForm.fs:181-203
             let mutable d = data
-            { Form = SdfForm.Primitive.torus data; Node = Native.check (Native.ft_form_torus (Native.ctx.Value, &d)) }
-        let triangle (data : SdfForm.Primitive.Triangle) =                                       // SdfForm.fs:214-268
+            { Form = FrayTracer.SdfForm.Primitive.torus data; Node = Native.check (Native.ft_form_torus (Native.ctx.Value, &d)) }
+        let triangle (data : FrayTracer.SdfForm.Primitive.Triangle) =                                       // SdfForm.fs:214-268
             let mutable d = data
-            { Form = SdfForm.Primitive.triangle data; Node = Native.check (Native.ft_form_triangle (Native.ctx.Value, &d)) }
+            { Form = FrayTracer.SdfForm.Primitive.triangle data; Node = Native.check (Native.ft_form_triangle (Native.ctx.Value, &d)) }
 
     let union (forms : seq<GpuForm>) =                                                           // SdfForm.fs:14-40
         match forms |> Seq.toArray with
         | [||] -> failwith "No SdfObjects given."
         | [| form |] -> form
         | forms ->
-            { Form = forms |> Seq.map (fun f -> f.Form) |> SdfForm.union
+            { Form = forms |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.union
               Node = Native.check (Native.ft_form_union (c (), nodes forms, forms.Length)) }
 
     let subtract (a : GpuForm) (b : GpuForm) =                                                   // SdfForm.fs:42-49
-        { Form = SdfForm.subtract a.Form b.Form; Node = Native.check (Native.ft_form_subtract (c (), a.Node, b.Node)) }
+        { Form = FrayTracer.SdfForm.subtract a.Form b.Form; Node = Native.check (Native.ft_form_subtract (c (), a.Node, b.Node)) }
 
     let intersect (forms : seq<GpuForm>) =                                                       // SdfForm.fs:51-67
         match forms |> Seq.toArray with
         | [||] -> failwith "No SdfObjects given."
         | [| form |] -> form
         | forms ->
-            { Form = forms |> Seq.map (fun f -> f.Form) |> SdfForm.intersect
+            { Form = forms |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.intersect
               Node = Native.check (Native.ft_form_intersect (c (), nodes forms, forms.Length)) }
 
     let unionSmooth (strength : float32) (forms : seq<GpuForm>) =                                // SdfForm.fs:69-91
@@ -149,27 +162,27 @@ module SdfForm =
         | [||] -> failwithf "blub"
         | [| sdf |] -> sdf
         | sdfs ->
-            { Form = sdfs |> Seq.map (fun f -> f.Form) |> SdfForm.unionSmooth strength
+            { Form = sdfs |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.unionSmooth strength
               Node = Native.check (Native.ft_form_union_smooth (c (), strength, nodes sdfs, sdfs.Length)) }
 
 [<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
 module SdfMaterial =
     let createSolid (color : FColor) =                                                           // SdfMaterial.fs:4-7
         let mutable rgb = let (FColor v) = color in v
-        { Material = SdfMaterial.createSolid color; Node = Native.check (Native.ft_material_solid (Native.ctx.Value, &rgb)) }
+        { Material = FrayTracer.SdfMaterial.createSolid color; Node = Native.check (Native.ft_material_solid (Native.ctx.Value, &rgb)) }
 
     /// EXTENSION (no reference counterpart): glass.  The CPU closure is the solid tint (what the device renders
     /// with MaxBounces = 0); refraction exists on the device path only.
     let createGlass (tint : FColor) (ior : float32) (dispersion : float32) =
         let mutable rgb = let (FColor v) = tint in v
-        { Material = SdfMaterial.createSolid tint; Node = Native.check (Native.ft_material_glass (Native.ctx.Value, &rgb, ior, dispersion)) }
+        { Material = FrayTracer.SdfMaterial.createSolid tint; Node = Native.check (Native.ft_material_glass (Native.ctx.Value, &rgb, ior, dispersion)) }
 
 [<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
 module SdfObject =
     let private c () = Native.ctx.Value
 
     let create (material : GpuMaterial) (form : GpuForm) : GpuObject =                           // SdfObject.fs:6-10
-        { Object = SdfObject.create material.Material form.Form
+        { Object = FrayTracer.SdfObject.create material.Material form.Form
           Node = Native.check (Native.ft_object_create (c (), material.Node, form.Node)) }
 
     let union (objects : seq<GpuObject>) : GpuObject =                                           // SdfObject.fs:12-48
@@ -178,17 +191,17 @@ module SdfObject =
         | [| o |] -> o
         | objects ->
             let nodes = objects |> Array.map (fun o -> o.Node)
-            { Object = objects |> Seq.map (fun o -> o.Object) |> SdfObject.union
+            { Object = objects |> Seq.map (fun o -> o.Object) |> FrayTracer.SdfObject.union
               Node = Native.check (Native.ft_object_union (c (), nodes, nodes.Length)) }
 
     let subtract (object : GpuObject) (form : GpuForm) : GpuObject =                             // SdfObject.fs:50-54
-        { Object = SdfObject.subtract object.Object form.Form
+        { Object = FrayTracer.SdfObject.subtract object.Object form.Form
           Node = Native.check (Native.ft_object_subtract (c (), object.Node, form.Node)) }
 
     let intersect (object : GpuObject) (forms : seq<GpuForm>) : GpuObject =                      // SdfObject.fs:56-64
         let forms = forms |> Seq.toArray
         let nodes = forms |> Array.map (fun f -> f.Node)
-        { Object = SdfObject.intersect object.Object (forms |> Seq.map (fun f -> f.Form))
+        { Object = FrayTracer.SdfObject.intersect object.Object (forms |> Seq.map (fun f -> f.Form))
           Node = Native.check (Native.ft_object_intersect (c (), object.Node, nodes, nodes.Length)) }
 
 [<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
@@ -196,13 +209,13 @@ module SdfLight =
     let directional (direction : Direction) (color : FColor) =                                   // SdfLight.fs:6-21
         let mutable d = direction
         let mutable rgb = let (FColor v) = color in v
-        { Light = SdfLight.directional direction color
+        { Light = FrayTracer.SdfLight.directional direction color
           Node = Native.check (Native.ft_light_directional (Native.ctx.Value, &d, &rgb)) }
 
     let point (position : Position) (color : FColor) =                                           // SdfLight.fs:23-42
         let mutable p = position
         let mutable rgb = let (FColor v) = color in v
-        { Light = SdfLight.point position color
+        { Light = FrayTracer.SdfLight.point position color
           Node = Native.check (Native.ft_light_point (Native.ctx.Value, &p, &rgb)) }
 
 module Trace =
@@ -213,7 +226,7 @@ module Trace =
         Native.check (Native.ft_scene_create (ctx, object.Node, &bg, [||], 0, &handle)) |> ignore
         try f handle finally Native.ft_scene_destroy handle
 
-    /// GPU sibling of `rays |> Array.map (SdfObject.tryTrace object)` (SdfObject.fs:66-78)
+    /// GPU sibling of `rays |> Array.map (FrayTracer.SdfObject.tryTrace object)` (SdfObject.fs:66-78)
     let objectTryTrace (object : GpuObject) (rays : Ray[]) : SdfObjectTraceResult voption[] =
         withObjectScene object (fun scene ->
             let out : FtObjectTraceResult[] = Array.zeroCreate rays.Length
@@ -223,7 +236,7 @@ module Trace =
                 if r.Hit = 0 then ValueNone
                 else ValueSome { SdfObjectTraceResult.Ray = r.Ray; Normal = r.Normal; Color = FColor r.Color }))
 
-    /// GPU sibling of `rays |> Array.map (SdfForm.tryTrace object.Form)` (SdfForm.fs:93-104)
+    /// GPU sibling of `rays |> Array.map (FrayTracer.SdfForm.tryTrace object.Form)` (SdfForm.fs:93-104)
     let formTryTrace (object : GpuObject) (rays : Ray[]) : SdfFormTraceResult voption[] =
         withObjectScene object (fun scene ->
             let out : FtFormTraceResult[] = Array.zeroCreate rays.Length
@@ -233,7 +246,7 @@ module Trace =
                 if r.Hit = 0 then ValueNone else ValueSome { SdfFormTraceResult.Ray = r.Ray; Distance = r.Distance }))
 
 module Image =
-    /// GPU sibling of `scene |> SdfScene.trace |> Image.render epsilon length imageSize camera`
+    /// GPU sibling of `scene |> FrayTracer.SdfScene.trace |> FrayTracer.Image.render epsilon length imageSize camera`
     /// (Image.fs:26-35 + SdfScene.fs:7-28).  Result layout = FColor[X,Y] as Array2D.Parallel.init makes it.
     let renderScene (epsilon : float32) (length : float32) (imageSize : ImageSize) (camera : Camera) (scene : GpuScene) : FColor[,] =
         let ctx = Native.ctx.Value
@@ -259,7 +272,7 @@ module Image =
         finally
             Native.ft_scene_destroy handle
 
-    /// GPU sibling of `image |> Image.toColors gamma rng` (Image.fs:37-50).  The reference draws its dithering noise from one
+    /// GPU sibling of `image |> FrayTracer.Image.toColors gamma rng` (Image.fs:37-50).  The reference draws its dithering noise from one
     /// System.Random shared by a parallel map (racy); here `seed = ValueNone` means no noise, `ValueSome s` a counter-based hash.
     let toColors (gamma : float32) (seed : uint32 voption) (image : FColor[,]) : System.Drawing.Color[,] =
         let X, Y = image.GetLength 0, image.GetLength 1
@@ -279,5 +292,5 @@ module Image =
         { FrayTracer.SdfScene.Object = scene.Object.Object
           BackgroundColor = scene.BackgroundColor
           Lights = scene.Lights |> List.map (fun l -> l.Light) }
-        |> SdfScene.trace
-        |> Image.render epsilon length imageSize camera
+        |> FrayTracer.SdfScene.trace
+        |> FrayTracer.Image.render epsilon length imageSize camera

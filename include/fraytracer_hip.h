@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 3
+#define FT_ABI_VERSION 4
 
 typedef enum ft_status {
     FT_OK = 0,
@@ -103,6 +103,19 @@ void ft_ctx_destroy(ft_ctx* ctx);
 const char* ft_last_error(void);
 /* use an existing HIP stream (e.g. torch's current stream) for all launches; NULL = own stream */
 int ft_ctx_set_stream(ft_ctx* ctx, void* hip_stream);
+/* "src=<hash>;kind=<product|profile|experiment>": hash of the sources this library was built from
+ * (fraytracer_amd/csrc/source_hash.py computes the same value from a source tree) and the kind of build. */
+const char* ft_build_info(void);
+/* Per-context switches (the library reads no environment variables).  FT_OPT_MATH selects the arithmetic of MathF.Exp / Log / Pow
+ * (below); every other option is for experiments and A/B measurements only and never changes a rendered bit. */
+typedef enum ft_option {
+    FT_OPT_REFILL_MIN = 1,        /* 1..64 (default 64): idle lanes a wave waits for before it takes new rays */
+    FT_OPT_MAX_BLOCKS_PER_CU = 2, /* 0 (default) = the occupancy limit; 1..8 caps the resident workgroups per CU */
+    FT_OPT_HOST_CHUNKS = 3,       /* 0 (default) = automatic; 1..16 column chunks of ft_render's host-output pipeline */
+    FT_OPT_HOST_PIN = 4           /* 1 (default): ft_render page-locks an unregistered destination for the call; 0: leaves it pageable */
+} ft_option;
+int ft_ctx_set_option(ft_ctx* ctx, int32_t option, int32_t value);
+int ft_ctx_get_option(const ft_ctx* ctx, int32_t option, int32_t* value);
 
 /* ---- scene construction: one entry per reference constructor ---------------------------- */
 ft_handle ft_form_sphere(ft_ctx*, const ft_sphere*);                       /* SdfForm.Primitive.sphere  SdfForm.fs:125-135 */

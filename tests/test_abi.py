@@ -35,7 +35,7 @@ def test_blittable_layouts_match_the_reference_records():
     assert C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Boundary) == 16 and C.sizeof(_lib.CameraS) == 48
     assert C.sizeof(_lib.Sphere) == 16 and C.sizeof(_lib.Capsule) == 28 and C.sizeof(_lib.Torus) == 32 and C.sizeof(_lib.Triangle) == 40
     assert C.sizeof(_lib.RenderParams) == 56 and C.sizeof(_lib.Stats) == 80
-    assert _lib.lib.ft_abi_version() == 3
+    assert _lib.lib.ft_abi_version() == 4
 
 
 def test_the_library_is_built_in_tree_and_is_not_the_oracle():
@@ -48,6 +48,39 @@ def test_the_library_is_built_in_tree_and_is_not_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 assert "oracle" not in open(os.path.join(dirpath, f), errors="ignore").read().replace("the oracle", "").replace("test oracle", "").replace("CPU oracle", ""), f
+
+
+def test_the_loaded_library_was_built_from_the_sources_next_to_it():
+    """ft_build_info() carries the hash of the sources the shared object was compiled from (csrc/source_hash.py, written into
+    build_hash.h by the Makefile).  A library left over from an experiment — edited sources rebuilt and then reverted, or a
+    `make profile` / `make experiment` build put in the product's place — fails here instead of quietly being the thing the GPU
+    suite and the bench measure (that happened in round 2: DESIGN.md section 10).  Also run on the GPU box (`-m gpu` selects
+    test_gpu_parity.py::test_product_build_is_the_one_under_test, which asserts the same)."""
+    info = ft.build_info()
+    assert info["kind"] == "product", info
+    assert info["src"] == ft.source_hash(), (info, ft.source_hash(), "rebuild: make -C fraytracer_amd/csrc")
+
+
+def test_the_library_reads_no_environment_variables():
+    """tuning switches are per-context options (ft_ctx_set_option), not hidden global state"""
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH], text=True)
+    assert not re.search(r"\b(secure_)?getenv\b", undefined), undefined
+    for f in ("capi.cpp", "scene.cpp", "multi.cpp", "kernels.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "fraytracer_amd", "csrc", f)).read(), f
+    host = ft.Device(-1)                       # options are plain context state: usable without a GPU
+    try:
+        assert host.get_option("refill_min") == 64 and host.get_option("host_pin") == 1
+        host.set_option("refill_min", 32); host.set_option("host_chunks", 2); host.set_option("host_pin", 0); host.set_option("max_blocks_per_cu", 3)
+        assert [host.get_option(k) for k in ("refill_min", "host_chunks", "host_pin", "max_blocks_per_cu")] == [32, 2, 0, 3]
+        for name, bad in (("refill_min", 0), ("refill_min", 65), ("host_chunks", 17), ("host_pin", 2), ("max_blocks_per_cu", -1)):
+            try:
+                host.set_option(name, bad)
+            except ft.FrayTracerError as e:
+                assert e.code == _lib.FT_ERR_INVALID
+            else:
+                raise AssertionError((name, bad))
+    finally:
+        host.close()
 
 
 C99_PROBE = r"""

@@ -32,6 +32,37 @@ def check_counts(gst, ocnt):
     assert gst["flags"] == ocnt["flags"] == 0
 
 
+def test_product_build_is_the_one_under_test(gpu):
+    """the library this GPU suite runs on is the product build of the sources that travelled with it (ft_build_info against
+    csrc/source_hash.py) — round 2 ran one suite on a stray experiment build without noticing"""
+    info = ft.build_info()
+    assert info["kind"] == "product" and info["src"] == ft.source_hash(), (info, ft.source_hash())
+
+
+def test_statistics_reset_is_ordered_with_the_next_launch(gpu, oracle):
+    """Regression for round 2's null-stream hipMemset of the statistics block (capi.cpp ft_collect_stats): the context's stream is
+    non-blocking, so the reset could still be pending when the next — here very short — launch added its counters.  300 tiny
+    renders back to back, each with the oracle's exact counters, on the context's own stream and on a caller's stream."""
+    import torch
+    scene, _ = syn.config2(seed=3, size=64)
+    ds, os_ = both(gpu, oracle, scene)
+    cam = syn.default_camera()
+    want = {}
+    for n in (8, 16, 24):
+        want[n] = os_.render(EPS, LEN, n, n, cam.as_array())[1]
+    side = torch.cuda.Stream()
+    try:
+        for rep in range(300):
+            if rep == 150:
+                gpu.set_stream(side.cuda_stream)
+            n = (8, 16, 24)[rep % 3]
+            _, st = ds.render(EPS, LEN, ft.ImageSize(n, n), cam)
+            for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow"):
+                assert st[k] == want[n][k], (rep, n, k, st[k], want[n][k])
+    finally:
+        gpu.set_stream(0)
+
+
 def test_math_exp_log_sqrt_div(gpu, oracle):
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-110, 92, 2_000_000), rng.uniform(-2, 2, 1_000_000),
@@ -271,17 +302,16 @@ def test_host_output_pipeline_is_bit_identical(gpu, oracle):
     """ft_render delivers the frame in host memory (Image.render returns a host FColor[,], Image.fs:26-35): large frames are
     rendered in column chunks on two streams while finished chunks are copied into the page-locked destination.  Registered,
     unregistered (pinned inside the call) and small (single-launch) frames all equal the frame left in HBM, bit for bit."""
-    import os
     scene, _ = syn.config2(seed=6, size=1536)
     cam = syn.default_camera()
     ds = gpu.scene(scene)
     for (W, H) in [(1536, 1024), (2048, 2048), (300, 5000), (64, 64)]:
         S = ft.ImageSize(W, H)
-        os.environ["FT_HOST_CHUNKS"] = "1"; os.environ["FT_HOST_NO_PIN"] = "1"      # one launch, one pageable copy after it
+        gpu.set_option("host_chunks", 1); gpu.set_option("host_pin", 0)            # one launch, one pageable copy after it
         try:
             want, st0 = ds.render(EPS, LEN, S, cam)
         finally:
-            del os.environ["FT_HOST_CHUNKS"], os.environ["FT_HOST_NO_PIN"]
+            gpu.set_option("host_chunks", 0); gpu.set_option("host_pin", 1)
         got, st = ds.render(EPS, LEN, S, cam)                      # fresh pageable array: pinned inside the call
         assert_bit_equal(got, want, f"{W}x{H} pageable")
         for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "sdf_evals"):
@@ -769,13 +799,17 @@ def test_tone_map_on_the_device_matches_the_oracle(gpu, oracle):
     for (X, Y) in [(64, 64), (37, 101), (130, 19), (1, 1), (200, 65)]:
         img = (rng.random((X, Y, 3)) ** 3 * 4.0).astype(np.float32)
         if X > 30:
-            img[3, 2] = (np.nan, 0.0, -1.0); img[7, 1] = (np.inf, 1e30, 1e-30); img[9, 0] = 0.0
+            img[3, 2] = (np.nan, 0.0, -1.0); img[7, 1] = (1e30, 1e-30, 3.0); img[9, 0] = 0.0
+            # a pixel with a NaN channel is skipped WHOLE by the max (MathF.Max propagates NaN, Seq.max then keeps `acc`,
+            # Math.fs:83 / Array2D.fs:45-50): its 5e30 must not become the normalisation although it is the largest channel
+            img[5, 3] = (np.nan, 5e30, 0.0); img[11, 4] = (2.0, np.nan, 7e30)
         for gamma in (2.2, 1.0):
             for seed in (None, 19):
                 for bmp in (False, True):
                     want, wmx = oracle.tone_map(img, gamma=gamma, seed=seed, bmp_order=bmp)
                     got = ft.Image.toColors(gamma, seed, img, gpu, bmp_order=bmp)
                     assert got.shape == want.shape and np.array_equal(got, want), (X, Y, gamma, seed, bmp)
+                    if X > 30: assert wmx == np.float32(1e30)
     z = ft.Image.toColors(2.2, None, np.zeros((16, 8, 3), np.float32), gpu)
     assert z.max() == 0
     # end to end: Program.fs:90-100 — render + toColors on the device, 3 bytes per pixel come back

@@ -117,6 +117,33 @@ def test_errors_are_reported_not_swallowed(host):
         assert e.value.code == ft._lib.FT_ERR_NO_DEVICE
 
 
+def test_render_multi_validates_its_arguments_without_a_gpu(host):
+    """ft_render_multi (multi.cpp): null arrays, width not a multiple of stripe_width x n, and host-only contexts are refused
+    before any device or RCCL call — FT_ERR_INVALID / FT_ERR_UNSUPPORTED / FT_ERR_NO_DEVICE (there is no CPU path)"""
+    import ctypes as C
+    from fraytracer_amd import _lib
+    lib = _lib.lib
+    ds = host.scene(syn.config1()[0])
+    cam = syn.default_camera()
+    out = np.zeros((64, 8, 3), np.float32)
+    st = _lib.Stats()
+
+    def call(ctxs, scenes, n, W=64, H=8, stripe=16, outp=out.ctypes.data_as(C.c_void_p), camp=None):
+        p = _lib.RenderParams(W, H, 0, W, stripe, 1, 0, 1, 0.01, 30.0, 0, 0.0, 0, 0)
+        return lib.ft_render_multi(ctxs, scenes, n, camp if camp is not None else C.byref(cam._c), C.byref(p), outp, C.byref(st))
+
+    two_ctx = (C.c_void_p * 2)(host._ctx, host._ctx)
+    two_sc = (C.c_void_p * 2)(ds._scene, ds._scene)
+    assert call(None, two_sc, 2) == _lib.FT_ERR_INVALID and call(two_ctx, None, 2) == _lib.FT_ERR_INVALID
+    assert call(two_ctx, two_sc, 0) == _lib.FT_ERR_INVALID and call(two_ctx, two_sc, 2, outp=None) == _lib.FT_ERR_INVALID
+    assert call(two_ctx, two_sc, 2, W=0) == _lib.FT_ERR_INVALID and call(two_ctx, two_sc, 2, stripe=-4) == _lib.FT_ERR_INVALID
+    assert call(two_ctx, two_sc, 2, W=72) == _lib.FT_ERR_UNSUPPORTED and "multiple of stripe_width" in _lib.last_error()
+    assert call((C.c_void_p * 2)(host._ctx, None), two_sc, 2) == _lib.FT_ERR_INVALID
+    assert call(two_ctx, (C.c_void_p * 2)(ds._scene, None), 2) == _lib.FT_ERR_INVALID
+    assert call(two_ctx, two_sc, 2) == _lib.FT_ERR_NO_DEVICE and "no CPU fallback" in _lib.last_error()
+    assert call(two_ctx, two_sc, 1) == _lib.FT_ERR_NO_DEVICE
+
+
 def test_host_side_mirrors_of_the_small_reference_functions(oracle):
     """ImageSize.getUniformPixelPos / Camera.uniformPixelToRay (Image.fs:17-23, Camera.fs:44-54) and Ray.get / move /
     setDirection (Ray.fs:6-15) of the Python mirror against the oracle's restatement, bit for bit"""

@@ -52,6 +52,15 @@ def test_tone_map_known_answers(oracle):
     out2, _ = oracle.tone_map(img2, gamma=1.0)
     for i, k in enumerate(ks):
         assert out2[i + 1, 0, 0] == (k if k % 2 == 0 else k + 1), k
+    # A pixel with a NaN channel does not take part in the normalisation at all, even when another of its channels is the largest
+    # value of the frame: getMaxColor = Max(Z, Max(Y, X)) with the NaN-propagating MathF.Max (Math.fs:83) is NaN for it, and
+    # Seq.max / Array.max keep `acc` unless `curr > acc` (Array2D.fs:45-50).  (In the reference a NaN at the head of a column sticks
+    # instead — position-dependent — and Color.FromArgb then throws for the NaN channel anyway; oracle and kernel skip the pixel.)
+    nanimg = np.zeros((4, 3, 3), F)
+    nanimg[1, 1] = (2.0, 1.0, 0.5); nanimg[2, 2] = (np.nan, 50.0, 0.0); nanimg[3, 0] = (1.0, 3.0, np.nan)
+    outn, mxn = oracle.tone_map(nanimg, gamma=1.0)
+    assert mxn == 2.0 and outn[1, 1].tolist() == [255, 128, 64]
+    assert outn[2, 2].tolist() == [0, 255, 0] and outn[3, 0].tolist() == [128, 255, 0]      # NaN byte = 0, 50 / 2 and 3 / 2 cap at 255
     # a black frame is normalised by 0.01, not by 0 (Image.fs:43); brighter-than-max cannot happen, 255 is the cap
     z, mz = oracle.tone_map(np.zeros((2, 2, 3), F))
     assert mz == F(0.01) and z.max() == 0

@@ -1,0 +1,16 @@
+"""Tools keep the old convenience of steering an experiment from the shell — FT_REFILL_MIN, FT_MAX_BLOCKS_PER_CU, FT_HOST_CHUNKS,
+FT_HOST_NO_PIN — but the LIBRARY no longer reads the environment: the tool reads the variable and sets the per-context option."""
+import os
+
+_ENV = {"FT_REFILL_MIN": ("refill_min", int), "FT_MAX_BLOCKS_PER_CU": ("max_blocks_per_cu", int), "FT_HOST_CHUNKS": ("host_chunks", int),
+        "FT_HOST_NO_PIN": ("host_pin", lambda v: 0 if v not in ("", "0") else 1), "FT_TAIL_MODE": ("tail_mode", int), "FT_MATH": ("math", int)}
+
+
+def apply_env_options(dev):
+    """-> {option: value} of what was applied"""
+    done = {}
+    for var, (name, conv) in _ENV.items():
+        if var in os.environ and name in dev.OPTIONS:
+            dev.set_option(name, conv(os.environ[var]))
+            done[name] = dev.get_option(name)
+    return done

@@ -14,6 +14,8 @@ import fraytracer_amd as ft
 from fraytracer_amd import synthetic as syn
 
 dev = ft.Device(0)
+from _opts import apply_env_options
+applied = apply_env_options(dev)
 cam = syn.default_camera()
 cases = [("C1 sphere 256^2", syn.config1()[0], 256), ("C2 union32 1024^2", syn.config2()[0], 1024),
          ("C2 union32+boxes 1024^2", syn.config2(boxes=True)[0], 1024),

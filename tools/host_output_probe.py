@@ -15,6 +15,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     scene, _ = syn.config3(size=size)
     cam = syn.default_camera()
     dev = ft.Device(0)
+    from _opts import apply_env_options
+    applied = apply_env_options(dev)
     ds = dev.scene(scene)
     S = ft.ImageSize(size, size)
     out = np.zeros((size, size, 3), np.float32)             # touched pages, like Array2D.zeroCreate

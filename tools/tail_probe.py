@@ -8,6 +8,8 @@ import fraytracer_amd as ft
 from fraytracer_amd import synthetic as syn, distributed as ftd
 
 dev = ft.Device(0)
+from _opts import apply_env_options
+applied = apply_env_options(dev)
 cam = syn.default_camera()
 W = 4096
 ds = dev.scene(syn.config3(size=W)[0])
@@ -23,5 +25,5 @@ for N in (1, 2, 4, 8):
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr(), **kw)
     st = ds.collect_stats()
     out[N] = round(st["kernel_ms"] / reps, 3)
-print(json.dumps({"cap": os.environ.get("FT_MAX_BLOCKS_PER_CU", "none"), "kernel_ms_per_rank_share": out,
+print(json.dumps({"options": applied, "kernel_ms_per_rank_share": out,
                   "efficiency_vs_N1": {n: round(out[1] / (n * out[n]), 3) for n in out}}))
