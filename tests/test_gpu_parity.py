@@ -43,24 +43,27 @@ def test_statistics_reset_is_ordered_with_the_next_launch(gpu, oracle):
     """Regression for round 2's null-stream hipMemset of the statistics block (capi.cpp ft_collect_stats): the context's stream is
     non-blocking, so the reset could still be pending when the next — here very short — launch added its counters.  300 tiny
     renders back to back, each with the oracle's exact counters, on the context's own stream and on a caller's stream."""
-    import torch
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")           # the runtime the library is linked against (already loaded: same instance)
+    side = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(side), 1) == 0          # hipStreamNonBlocking
     scene, _ = syn.config2(seed=3, size=64)
     ds, os_ = both(gpu, oracle, scene)
     cam = syn.default_camera()
     want = {}
     for n in (8, 16, 24):
         want[n] = os_.render(EPS, LEN, n, n, cam.as_array())[1]
-    side = torch.cuda.Stream()
     try:
         for rep in range(300):
             if rep == 150:
-                gpu.set_stream(side.cuda_stream)
+                gpu.set_stream(side.value)
             n = (8, 16, 24)[rep % 3]
             _, st = ds.render(EPS, LEN, ft.ImageSize(n, n), cam)
             for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow"):
                 assert st[k] == want[n][k], (rep, n, k, st[k], want[n][k])
     finally:
         gpu.set_stream(0)
+        hip.hipStreamDestroy(side)
 
 
 def test_math_exp_log_sqrt_div(gpu, oracle):
