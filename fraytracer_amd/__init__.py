@@ -6,7 +6,7 @@ Importing it fails if the shared library has not been built; there is no CPU fal
 """
 from ._lib import FrayTracerError, LIB_PATH, build_info, source_hash
 from .api import (FColor, SdfForm, SdfMaterial, SdfObject, SdfLight, SdfScene, Lens, Camera, ImageSize, Image, Ray,
-                  Device, DeviceScene, SceneTrace, realise, render_multi)
+                  Device, DeviceScene, SceneTrace, realise, render_multi, glibc_build_of_this_host)
 
 __all__ = ["FColor", "SdfForm", "SdfMaterial", "SdfObject", "SdfLight", "SdfScene", "Lens", "Camera", "ImageSize",
-           "Image", "Ray", "Device", "DeviceScene", "SceneTrace", "realise", "render_multi", "FrayTracerError", "LIB_PATH", "build_info", "source_hash"]
+           "Image", "Ray", "Device", "DeviceScene", "SceneTrace", "realise", "render_multi", "FrayTracerError", "LIB_PATH", "build_info", "source_hash", "glibc_build_of_this_host"]

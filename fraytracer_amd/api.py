@@ -311,6 +311,19 @@ def _vec(v):
     return _lib.Vec3(*v)
 
 
+def glibc_build_of_this_host():
+    """FT_MATH_GLIBC_FMA (1) or FT_MATH_GLIBC_SSE2 (2): which build of expf / logf / powf the C runtime of this machine resolves to —
+    glibc's x86-64 ifunc takes the FMA build iff the CPU has FMA and AVX2 (and no GLIBC_TUNABLES entry masks them).  The value to give
+    Device.set_option("math", ...) for results that equal the reference's CPU path on this host."""
+    import os
+    try:
+        flags = open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split()
+    except (OSError, IndexError):
+        return _lib.FT_MATH_GLIBC_FMA
+    tun = os.environ.get("GLIBC_TUNABLES", "")
+    return _lib.FT_MATH_GLIBC_FMA if ("fma" in flags and "avx2" in flags and "-FMA" not in tun and "-AVX2" not in tun) else _lib.FT_MATH_GLIBC_SSE2
+
+
 class Device:
     """One ft_ctx: a GPU (index >= 0) or a host-only context (index -1: construction and
     introspection only — rendering raises, there is no CPU fallback)."""
@@ -355,7 +368,7 @@ class Device:
         check(lib.ft_ctx_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
     OPTIONS = {"refill_min": _lib.FT_OPT_REFILL_MIN, "max_blocks_per_cu": _lib.FT_OPT_MAX_BLOCKS_PER_CU,
-               "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN}
+               "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN, "math": _lib.FT_OPT_MATH}
 
     def set_option(self, name, value):
         """ft_ctx_set_option: per-context switches (the library reads no environment variables)"""
@@ -404,6 +417,12 @@ class Device:
                 scene._realised[self.serial] = got
                 self._scenes.append(got)
             return got
+
+    def selftest_libm(self, op, variant, y=0.0, lo_bits=0, n_chunks=256):
+        """ft_selftest_libm: checksums of the device restatement of glibc's expf (op 0) / logf (1) / powf(x, y) (2) per 2^24 inputs"""
+        sums = (C.c_uint64 * n_chunks)()
+        check(lib.ft_selftest_libm(self._ctx, int(op), int(variant), float(y), int(lo_bits), int(n_chunks), sums))
+        return np.array(sums, np.uint64)
 
     def selftest_fastmath(self):
         m = (C.c_uint64 * 3)()

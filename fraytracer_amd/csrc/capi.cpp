@@ -11,6 +11,7 @@
 #include "../../include/fraytracer_hip.h"
 #include "build_hash.h"      // FT_SOURCE_HASH: written by the Makefile (source_hash.py)
 #include "ft_kernels.h"
+#include "ft_libm.h"         // FT_LIBM_TAB_DOUBLES (LDS footprint of the *_libm kernels)
 #include "scene.hpp"
 
 #ifndef FT_BUILD_KIND
@@ -55,6 +56,7 @@ struct ft_ctx {
     int optMaxBlocksPerCU = 0;                             // 0: the occupancy limit
     int optHostChunks = 0;                                 // 0: automatic (4 for frames >= 16 MB)
     int optHostPin = 1;                                    // page-lock an unregistered ft_render destination for the call
+    int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
 };
 
 struct ft_scene {
@@ -63,6 +65,7 @@ struct ft_scene {
     void* dBlob = nullptr;
     FtSceneDev dev{};
     const float* dMaterialsExt = nullptr;    // EXTENSION table, handed to the kernel through FtRenderArgs
+    bool usesExpLog = false;                 // the program has a unionSmooth (SdfForm.fs:80,82): the only place FT_OPT_MATH matters while tracing
 };
 
 namespace {
@@ -191,8 +194,14 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     return FT_OK;
 }
 
-// statistics header, per-lane value slots (distance + material index), the staged constant-pool prefix
-size_t ldsBytes(const ft_scene* s) { return (size_t)FT_LDS_HDR_FLOATS * 4 + (size_t)s->dev.nSlots * FT_BLOCK * 8 + (size_t)s->dev.nStage * 4; }
+// statistics header, per-lane value slots (distance + material index), the staged constant-pool prefix; the *_libm kernels keep glibc's
+// tables behind that, 8-byte aligned (kernels.hip ft_libm_lds_offset)
+size_t ldsBytes(const ft_scene* s, bool libm = false) {
+    const size_t floats = (size_t)FT_LDS_HDR_FLOATS + (size_t)s->dev.nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
+    return libm ? ((floats + 1) & ~(size_t)1) * 4 + (size_t)FT_LIBM_TAB_DOUBLES * 8 : floats * 4;
+}
+// does this launch take the glibc build of the kernels?
+bool libmLaunch(const ft_ctx* c, const ft_scene* s) { return c->optMath != FT_MATH_FIXED && s->usesExpLog; }
 
 // A frame loop that never calls ft_collect_stats must not grow the event list: beyond this many pending pairs the
 // oldest one is folded into foldedMs (it has long completed: launches on one stream finish in order) and recycled.
@@ -224,7 +233,9 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     hipStream_t stream = lane ? c->lane1 : c->stream;
     uint32_t* counter = c->dCounter + (lane ? 16 : 0);
     int perCU = 0;
-    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, ldsBytes(s), &perCU));
+    const bool libm = libmLaunch(c, s);
+    const size_t lds = ldsBytes(s, libm);
+    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, libm, lds, &perCU));
     perCU = std::max(1, std::min(perCU, 8));
     if (c->optMaxBlocksPerCU > 0) perCU = std::min(perCU, c->optMaxBlocksPerCU);       // FT_OPT_MAX_BLOCKS_PER_CU (experiments only)
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
@@ -242,13 +253,15 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
+    a.math = libm ? 1u : 0u;
+    a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
     a.materialsExt = s->dMaterialsExt;
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
     hipEvent_t e0, e1;
     int rc = foldOldestEvents(c); if (rc) return rc;
     if ((rc = acquireEvents(c, e0, e1))) return rc;
     HIP_TRY(hipEventRecord(e0, stream));
-    HIP_TRY(ft_launch_trace(&a, blocks, ldsBytes(s), stream));
+    HIP_TRY(ft_launch_trace(&a, blocks, lds, stream));
     HIP_TRY(hipEventRecord(e1, stream));
     c->events.emplace_back(e0, e1);
     return FT_OK;
@@ -289,6 +302,9 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_MAX_BLOCKS_PER_CU: if (value < 0 || value > 8) return setErr(FT_ERR_INVALID, "FT_OPT_MAX_BLOCKS_PER_CU: 0 (no cap) .. 8"); c->optMaxBlocksPerCU = value; return FT_OK;
     case FT_OPT_HOST_CHUNKS: if (value < 0 || value > 16) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_CHUNKS: 0 (automatic) .. 16"); c->optHostChunks = value; return FT_OK;
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
+    case FT_OPT_MATH:
+        if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
+        c->optMath = value; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
 }
@@ -299,6 +315,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_MAX_BLOCKS_PER_CU: *value = c->optMaxBlocksPerCU; return FT_OK;
     case FT_OPT_HOST_CHUNKS: *value = c->optHostChunks; return FT_OK;
     case FT_OPT_HOST_PIN: *value = c->optHostPin; return FT_OK;
+    case FT_OPT_MATH: *value = c->optMath; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
 }
@@ -445,6 +462,8 @@ int ft_scene_create(ft_ctx* c, ft_handle object, const float bg[3], const ft_han
     if (s->flat.items.size() >= (1ull << 27) || s->flat.consts.size() >= (1ull << 30)) {
         delete s; return setErr(FT_ERR_UNSUPPORTED, "scene has 2^27 or more (cell, candidate) records or 2^30 or more constants");
     }
+    for (const FtInstr& in : s->flat.instr)
+        if (in.op == FT_OP_SMOOTH_RUN || in.op == FT_OP_SMOOTH_ADD || in.op == FT_OP_SMOOTH_FIN) s->usesExpLog = true;
     int rc = uploadScene(c, s);
     if (rc) { delete s; return rc; }
     *out = s;
@@ -456,6 +475,7 @@ int ft_scene_clone(const ft_scene* src, ft_ctx* dst, ft_scene** out) {
     ft_scene* s = new ft_scene();
     s->ctx = dst;
     s->flat = src->flat;
+    s->usesExpLog = src->usesExpLog;
     int rc = uploadScene(dst, s);
     if (rc) { delete s; return rc; }
     *out = s;
@@ -693,7 +713,7 @@ int ft_tone_map_device(ft_ctx* c, const void* d_frame, int32_t X, int32_t Y, con
     if ((rc = ensureAux(c, 256))) return rc;
     const float gammaInv = 1.0f / p->gamma;                            // Image.fs:38
     HIP_TRY(ft_launch_tonemap(static_cast<const float*>(d_frame), (uint32_t)X, (uint32_t)Y, static_cast<uint32_t*>(c->aux), gammaInv,
-                              p->dither ? 1u : 0u, p->seed, p->bmp_order != 0, static_cast<unsigned char*>(d_out), (unsigned)c->numCUs, c->stream));
+                              p->dither ? 1u : 0u, p->seed, p->bmp_order != 0, static_cast<unsigned char*>(d_out), (unsigned)c->numCUs, c->optMath, c->stream));
     return FT_OK;
 }
 
@@ -786,8 +806,11 @@ int ft_eval_distance(ft_ctx* c, const ft_scene* s, const ft_vec3* pts, int64_t n
     unsigned char* base = static_cast<unsigned char*>(c->scratch);
     HIP_TRY(hipMemcpyAsync(base, pts, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
     const unsigned blocks = (unsigned)std::min<int64_t>((n + FT_BLOCK - 1) / FT_BLOCK, (int64_t)c->numCUs * 8);
-    HIP_TRY(ft_launch_eval_points(&s->dev, reinterpret_cast<const float*>(base), n, reinterpret_cast<float*>(base + pBytes),
-                                  reinterpret_cast<int*>(base + pBytes + dBytes), blocks, ldsBytes(s), c->stream));
+    const bool libm = libmLaunch(c, s);
+    FtSceneDev dev = s->dev;
+    dev.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
+    HIP_TRY(ft_launch_eval_points(&dev, libm ? 1 : 0, reinterpret_cast<const float*>(base), n, reinterpret_cast<float*>(base + pBytes),
+                                  reinterpret_cast<int*>(base + pBytes + dBytes), blocks, ldsBytes(s, libm), c->stream));
     HIP_TRY(hipMemcpyAsync(outD, base + pBytes, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (outM) HIP_TRY(hipMemcpyAsync(outM, base + pBytes + dBytes, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -796,7 +819,7 @@ int ft_eval_distance(ft_ctx* c, const ft_scene* s, const ft_vec3* pts, int64_t n
 
 int ft_math_eval(ft_ctx* c, int32_t op, const float* x, const float* y, int64_t n, float* out) {
     int rc = requireDevice(c); if (rc) return rc;
-    if (!x || !out || n < 0 || op < 0 || op > 5 || (op == 3 && !y)) return setErr(FT_ERR_INVALID, "bad argument");
+    if (!x || !out || n < 0 || op < 0 || op > 12 || ((op == 3 || op >= 10) && !y)) return setErr(FT_ERR_INVALID, "bad argument");
     if (n == 0) return FT_OK;
     const size_t b = align256((size_t)n * 4);
     if ((rc = ensureScratch(c, 3 * b))) return rc;
@@ -831,6 +854,19 @@ int ft_selftest_fastmath(ft_ctx* c, uint64_t mismatches[3]) {
     HIP_TRY(hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     mismatches[0] = h[0]; mismatches[1] = h[1]; mismatches[2] = h[2];
+    return FT_OK;
+}
+
+int ft_selftest_libm(ft_ctx* c, int32_t op, int32_t variant, float y, uint32_t lo_bits, int32_t n_chunks, uint64_t* sums) {
+    int rc = requireDevice(c); if (rc) return rc;
+    if (!sums || op < 0 || op > 2 || (variant != FT_MATH_GLIBC_FMA && variant != FT_MATH_GLIBC_SSE2) || n_chunks < 1 || n_chunks > 256 ||
+        (uint64_t)lo_bits + ((uint64_t)n_chunks << 24) > (1ull << 32)) return setErr(FT_ERR_INVALID, "bad argument");
+    if ((rc = ensureScratch(c, (size_t)n_chunks * 8))) return rc;
+    unsigned long long* d = static_cast<unsigned long long*>(c->scratch);
+    HIP_TRY(hipMemsetAsync(d, 0, (size_t)n_chunks * 8, c->stream));
+    HIP_TRY(ft_launch_libm_checksum(op, variant, y, lo_bits, (uint32_t)n_chunks, d, c->stream));
+    HIP_TRY(hipMemcpyAsync(sums, d, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return FT_OK;
 }
 

@@ -98,7 +98,9 @@ struct FtSceneDev {             // passed by value as kernel argument
     uint32_t nStage;            // leading floats of consts[] that every workgroup stages into LDS
     float nearR2;               // |p|^2 <= nearR2  =>  every t of the fast sphere runs is >= -87 (exp result normal)
     uint32_t fastQ;             // 1: every union candidate admits the clamped fast sqrt (scene.cpp: unionFastQ)
-    uint32_t nGlass, pad2;      // EXTENSION: glass materials in the scene
+    uint32_t nGlass;            // EXTENSION: glass materials in the scene
+    uint32_t mathFma;           // FT_OPT_MATH (set per launch, not by the flattener): 1 = glibc's FMA build of expf / logf, 0 = its SSE2 build
+                                // (read by the *_libm kernels only)
 };
 
 struct FtStatsDev {

@@ -34,6 +34,8 @@ struct FtRenderArgs {
     uint32_t maxBounces;      // EXTENSION glass: interactions per path; 0 = glass shades as a solid
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
     uint32_t refillMin;       // idle lanes a wave waits for before it takes new rays (1 = refill at once; kernels.hip "Burst refill")
+    uint32_t math;            // 0: the default kernels; 1: launch the *_libm build (FT_OPT_MATH = glibc and the scene has a unionSmooth)
+    uint32_t pad2;
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move
     float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)
@@ -43,9 +45,12 @@ struct FtRenderArgs {
 extern "C" {
 #endif
 hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st);
-hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
+hipError_t ft_launch_eval_points(const FtSceneDev* S, int math, const float* pts, long long n, float* outD, int* outM,
                                  unsigned blocks, size_t ldsBytes, hipStream_t st);
 hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st);
+// ft_selftest_libm: per chunk of 2^24 consecutive float bit patterns starting at lo, the sum of splitmix64(input bits << 32 | result bits)
+// of the device restatement of glibc's expf (op 0) / logf (1) / powf(x, y) (2); variant 1 = FMA build, 2 = SSE2 build
+hipError_t ft_launch_libm_checksum(int op, int variant, float y, uint32_t lo, uint32_t nChunks, unsigned long long* d_sums, hipStream_t st);
 // device-side buildSpatialLookup (SdfBoundary.fs:245-274): one workgroup per cell
 struct FtGridBuildArgs {
     const float* bounds;      // n x (cx, cy, cz, r)
@@ -62,11 +67,11 @@ hipError_t ft_launch_grid_compact(const FtItem* tmp, const uint32_t* cellStart, 
 hipError_t ft_launch_resolve(const float* planes, float* out, unsigned long long nFloats, unsigned spp, hipStream_t st);
 // Image.toColors (+ toBitmap order) on the device: max pass + map pass on one stream; maxBits = 4 bytes of device scratch
 hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_t* maxBits, float gammaInv, uint32_t dither, uint32_t seed,
-                             int bmpOrder, unsigned char* out, unsigned numCUs, hipStream_t st);
+                             int bmpOrder, unsigned char* out, unsigned numCUs, int math, hipStream_t st);   // math: FT_OPT_MATH (0 fixed pow, 1 / 2 glibc powf)
 // ft_render_multi: gathered slabs [rank][stripe][...] -> frame [stripe][rank][...] on the device
 hipError_t ft_launch_deinterleave(const float* recv, float* frame, unsigned long long stripeFloats, uint32_t nStripes, uint32_t nRanks, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
-hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU);
+hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 #include "ft_device.h"
 #include "ft_kernels.h"
 #include "ft_math.h"
+#include "ft_libm.h"
 
 // ------------------------------------------------------------------------------------------------
 // primitives (SdfForm.fs:125-268).  `c` points at the primitive's constant-pool record; when the
@@ -77,6 +78,23 @@ __device__ __forceinline__ void ft_count(uint32_t k) {
 }
 __device__ __forceinline__ void ft_flag(uint32_t bits) {
     __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + FT_C_FLAGS * FT_BLOCK, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- arithmetic of MathF.Exp / MathF.Log (FT_OPT_MATH) ------------------------------------------------------------------------
+// MATH = 0: the fixed algorithms of ft_math.h (same bits on every machine; the default).  MATH = 1: glibc's expf / logf restated
+// (ft_libm.h) — what the reference's MathF.Exp / Log (SdfForm.fs:80,82) return under .NET on Linux x86-64.  The MATH = 1 kernels are
+// separate instantiations (the default kernels carry no double-precision code); which of glibc's two builds — FMA or SSE2 — is the
+// wave-uniform FtSceneDev.mathFma.  The 640-byte table block sits in LDS behind the staged constants (8-byte aligned).
+__device__ const ft_u64 ft_libm_tab_g[FT_LIBM_TAB_DOUBLES] = FT_LIBM_TAB_INIT;
+__device__ __forceinline__ uint32_t ft_libm_lds_offset(const FtSceneDev& S) { return (FT_LDS_HDR_FLOATS + 2u * S.nSlots * FT_BLOCK + S.nStage + 1u) & ~1u; }
+__device__ __forceinline__ const ft_u64* ft_libm_tab(const FtSceneDev& S) { return reinterpret_cast<const ft_u64*>(ft_lds + ft_libm_lds_offset(S)); }
+template <int MATH> __device__ __forceinline__ float ft_exp_m(float x, const FtSceneDev& S) {
+    if (MATH == 0) return ft_exp(x);
+    return S.mathFma ? ft_glibc_expf<true>(x, ft_libm_tab(S)) : ft_glibc_expf<false>(x, ft_libm_tab(S));
+}
+template <int MATH> __device__ __forceinline__ float ft_log_m(float x, const FtSceneDev& S) {
+    if (MATH == 0) return ft_log(x);
+    return S.mathFma ? ft_glibc_logf<true>(x, ft_libm_tab(S)) : ft_glibc_logf<false>(x, ft_libm_tab(S));
 }
 
 // ---- square roots -----------------------------------------------------------------------------------------
@@ -312,6 +330,34 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
     return sum;
 }
 
+// The same run with glibc's expf (FT_OPT_MATH, MATH = 1 kernels): sum += expf(si * (|c_i - p| - r_i)).  FQ: the evaluation passed fast_point_ok and
+// the run the flatten-time bounds, so the clamped five-instruction root equals sqrtf (as in the loop above); the exponential is the full
+// restatement, special cases included, so no range precondition is needed.  Four children per trip: their double-precision chains interleave.
+template <bool FMA, bool FQ>
+__device__ __forceinline__ float smooth_run_spheres_libm(const float* __restrict__ ldsC, uint32_t count, float si, f3 p, float sum, const ft_u64* __restrict__ tab) {
+    uint32_t i = 0;
+    for (; i + 4u <= count; i += 4u) {
+        float4 prm[4];
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prm[j] = *reinterpret_cast<const float4*>(ldsC + 4 * (i + j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
+            const float q = (dx * dx + dy * dy) + dz * dz;
+            e[j] = ft_glibc_expf<FMA>(si * (ft_sq<FQ>(q) - prm[j].w), tab);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum = sum + e[j];
+    }
+    for (; i < count; ++i) {
+        const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
+        const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
+        sum = sum + ft_glibc_expf<FMA>(si * (ft_sq<FQ>((dx * dx + dy * dy) + dz * dz) - prm.w), tab);
+    }
+    return sum;
+}
+
 // wave-uniform: are all active lanes inside the radius where every exponential of the fast runs is normal?
 __device__ __forceinline__ bool near_point_ok(f3 p, float nearR2) {
     const float pp = p.x * p.x + p.y * p.y + p.z * p.z;               // any rounding is covered by the margin in nearR2
@@ -434,11 +480,11 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
 
 // the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
-template <bool WITH_UNION, bool CALLS>
+template <bool WITH_UNION, bool CALLS, int MATH>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
                                         uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk);
 
-template <bool FQ>
+template <bool FQ, int MATH>
 __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            float* __restrict__ sd, uint32_t* __restrict__ sl, const float* __restrict__ ldsC,
                                            bool fastOk, bool nearOk, float& outD, uint32_t& outLeaf) {
@@ -485,7 +531,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
                 if (pending && data == k) {
                     const uint32_t FT_CONST* cr = reinterpret_cast<const uint32_t FT_CONST*>(consts + k);   // (first instr, end instr, slot)
                     const uint32_t slot = cr[2];
-                    ft_exec<false, false>(S, cr[0], cr[1], p, sd, sl, ldsC, fastOk, nearOk);
+                    ft_exec<false, false, MATH>(S, cr[0], cr[1], p, sd, sl, ldsC, fastOk, nearOk);
                     d = sd[slot * FT_BLOCK]; l = sl[slot * FT_BLOCK];
                     pending = false;
                 }
@@ -506,7 +552,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
 // word s*FT_BLOCK + t: conflict-free).  Returns scene.Object.Form.Distance(p) and the material
 // the reference's material closure would pick at p.
 // ------------------------------------------------------------------------------------------------
-template <bool WITH_UNION, bool CALLS>
+template <bool WITH_UNION, bool CALLS, int MATH>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
                                         uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk) {
     cfp consts = as_const(S.consts);
@@ -523,24 +569,26 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
         case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
             float sum = (in.flags & 1u) ? 0.0f : *dst;
             if (fastOk && S.nStage != 0 && (in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
-                sum = nearOk ? smooth_run_spheres_fast<true>(ldsC + in.data, in.count, in.f0, p, sum)
-                             : smooth_run_spheres_fast<false>(ldsC + in.data, in.count, in.f0, p, sum);
+                if (MATH != 0) sum = S.mathFma ? smooth_run_spheres_libm<true, true>(ldsC + in.data, in.count, in.f0, p, sum, ft_libm_tab(S))
+                                               : smooth_run_spheres_libm<false, true>(ldsC + in.data, in.count, in.f0, p, sum, ft_libm_tab(S));
+                else sum = nearOk ? smooth_run_spheres_fast<true>(ldsC + in.data, in.count, in.f0, p, sum)
+                                  : smooth_run_spheres_fast<false>(ldsC + in.data, in.count, in.f0, p, sum);
             } else {
                 cfp c = consts + in.data;
                 const uint32_t stride = prim_stride(in.type);
                 for (uint32_t i = 0; i < in.count; ++i)
-                    sum = sum + ft_exp(in.f0 * prim_eval(in.type, c + i * stride, p));
+                    sum = sum + ft_exp_m<MATH>(in.f0 * prim_eval(in.type, c + i * stride, p), S);
             }
             *dst = sum;
             break;
         }
         case FT_OP_SMOOTH_ADD: {
             const float sum = (in.flags & 1u) ? 0.0f : *dst;
-            *dst = sum + ft_exp(in.f0 * sd[in.src * FT_BLOCK]);
+            *dst = sum + ft_exp_m<MATH>(in.f0 * sd[in.src * FT_BLOCK], S);
             break;
         }
         case FT_OP_SMOOTH_FIN:                                         // SdfForm.fs:82
-            *dst = -ft_log(*dst) * in.f0;
+            *dst = -ft_log_m<MATH>(*dst, S) * in.f0;
             break;
         case FT_OP_SUBTRACT:                                           // SdfForm.fs:46-47
             *dst = ft_max(-(sd[in.src * FT_BLOCK]), *dst);
@@ -565,8 +613,8 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
             if constexpr (WITH_UNION) {
                 float d; uint32_t l;
                 if constexpr (CALLS) {                                 // scenes with sub-program children (FtSceneDev.fastPath == 2)
-                    if (fastOk && S.fastQ) eval_union<true>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
-                    else eval_union<false>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                    if (fastOk && S.fastQ) eval_union<true, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                    else eval_union<false, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                 } else {
                     if (fastOk && S.fastQ) eval_union_prims<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
                     else eval_union_prims<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
@@ -580,12 +628,12 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
     }
 }
 
-template <bool CALLS>
+template <bool CALLS, int MATH>
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
                                         const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
     const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
-    const bool nearOk = fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    ft_exec<true, CALLS>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
+    const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
+    ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -593,18 +641,26 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
 // Lean evaluator for scenes whose whole program is {fast sphere SMOOTH_RUN..., SMOOTH_FIN, SETLEAF}
 // (FtSceneDev.fastPath == 1, decided when the scene is flattened): the accumulator lives in a VGPR,
 // no value slots, no primitive switch — the kernel variant built on it needs far fewer registers.
+template <int MATH>
 __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, const f3 p, const float* __restrict__ ldsC,
                                                        float& outD, uint32_t& outLeaf) {
     float acc = 0.0f;
     uint32_t leaf = 0;
     const bool fastOk = fast_point_ok(p);
-    const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
+    const bool nearOk = MATH == 0 && fastOk && near_point_ok(p, S.nearR2);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr FT_CONST* in = as_const(S.instr) + pc;
         const uint32_t op = in->op;
         if (op == FT_OP_SMOOTH_RUN) {
             const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
-            if (__builtin_expect(nearOk, 1)) {
+            if (MATH != 0) {                                           // FT_OPT_MATH: glibc's expf
+                const ft_u64* tab = ft_libm_tab(S);
+                if (S.mathFma) acc = fastOk ? smooth_run_spheres_libm<true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
+                                            : smooth_run_spheres_libm<true, false>(ldsC + in->data, in->count, in->f0, p, sum0, tab);
+                else acc = fastOk ? smooth_run_spheres_libm<false, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
+                                  : smooth_run_spheres_libm<false, false>(ldsC + in->data, in->count, in->f0, p, sum0, tab);
+            }
+            else if (__builtin_expect(nearOk, 1)) {
 #ifndef FT_SQRT_5
                 const int pw = ft_strength_pw(in->f0);                 // wave-uniform: the strength is an instruction field
                 if (pw == 2) acc = smooth_run_spheres_fast<true, 2>(ldsC + in->data, in->count, in->f0, p, sum0);
@@ -623,7 +679,7 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
                 }
             }
         }
-        else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log(acc) * in->f0;
+        else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log_m<MATH>(acc, S) * in->f0;
         else leaf = in->aux;                                           // FT_OP_SETLEAF
     }
     outD = acc; outLeaf = leaf;
@@ -861,7 +917,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return x;
 }
 
-template <int VARIANT, bool EXT>
+template <int VARIANT, bool EXT, int MATH = 0>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the first wave of block 0 reports the shader clock it ran at (statistics only); its start clocks wait in LDS, not in registers
@@ -871,6 +927,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + FT_LDS_HDR_FLOATS + a.S.nSlots * FT_BLOCK) + tid;
     float* ldsC = ft_lds + FT_LDS_HDR_FLOATS + 2u * a.S.nSlots * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
     for (uint32_t i = tid; i < a.S.nStage; i += FT_BLOCK) ldsC[i] = a.S.consts[i];
+    if (MATH != 0 && tid < FT_LIBM_TAB_DOUBLES) const_cast<ft_u64*>(ft_libm_tab(a.S))[tid] = ft_libm_tab_g[tid];   // FT_OPT_MATH: glibc's tables
     for (uint32_t k = 0; k < FT_LDS_STAT_ROWS; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
     __syncthreads();
 
@@ -928,8 +985,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             }
             float d; uint32_t leaf;
             FT_UDBG_T0(tEval);
-            if (VARIANT == 1) ft_eval_smooth_spheres(a.S, q, ldsC, d, leaf);
-            else ft_eval<VARIANT == 2>(a.S, q, sd, sl, ldsC, d, leaf);
+            if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf);
+            else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
             ft_count(FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
@@ -1043,22 +1100,39 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_sp
 // general scenes whose unions have combinator children evaluated on demand (FT_PR_CALL, FtSceneDev.fastPath == 2)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_CALLS_OCC ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
+// FT_OPT_MATH = glibc: the same six with MathF.Exp / Log as glibc's expf / logf (scenes that contain a unionSmooth only; every other scene
+// has no exponential and runs the kernels above whatever the option says)
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_libm(const FtRenderArgs a) { ft_trace_body<0, false, 1>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_libm(const FtRenderArgs a) { ft_trace_body<1, false, 1>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_ext_libm(const FtRenderArgs a) { ft_trace_body<0, true, 1>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_spheres_ext_libm(const FtRenderArgs a) { ft_trace_body<1, true, 1>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_libm(const FtRenderArgs a) { ft_trace_body<2, false, 1>(a); }
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext_libm(const FtRenderArgs a) { ft_trace_body<2, true, 1>(a); }
 
 // scene.Object.Form.Distance at explicit points (test / diagnostic entry)
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
-                                                                            long long n, float* __restrict__ outD, int* __restrict__ outM) {
+template <int MATH>
+__device__ __forceinline__ void ft_eval_points_body(const FtSceneDev& S, const float* __restrict__ pts, long long n, float* __restrict__ outD, int* __restrict__ outM) {
     const uint32_t tid = threadIdx.x;
     float* sd = ft_lds + FT_LDS_HDR_FLOATS + tid;                  // same LDS layout as the trace kernel (flag words first, unused here)
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + FT_LDS_HDR_FLOATS + S.nSlots * FT_BLOCK) + tid;
     float* ldsC = ft_lds + FT_LDS_HDR_FLOATS + 2u * S.nSlots * FT_BLOCK;
     for (uint32_t i = tid; i < S.nStage; i += FT_BLOCK) ldsC[i] = S.consts[i];
+    if (MATH != 0 && tid < FT_LIBM_TAB_DOUBLES) const_cast<ft_u64*>(ft_libm_tab(S))[tid] = ft_libm_tab_g[tid];
     __syncthreads();
     for (long long i = (long long)blockIdx.x * FT_BLOCK + tid; i < n; i += (long long)gridDim.x * FT_BLOCK) {
         float d; uint32_t leaf;
-        ft_eval<true>(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, ldsC, d, leaf);
+        ft_eval<true, MATH>(S, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sd, sl, ldsC, d, leaf);
         outD[i] = d;
         if (outM) outM[i] = (int)leaf;
     }
+}
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel(const FtSceneDev S, const float* __restrict__ pts,
+                                                                            long long n, float* __restrict__ outD, int* __restrict__ outM) {
+    ft_eval_points_body<0>(S, pts, n, outD, outM);
+}
+extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_eval_points_kernel_libm(const FtSceneDev S, const float* __restrict__ pts,
+                                                                                 long long n, float* __restrict__ outD, int* __restrict__ outM) {
+    ft_eval_points_body<1>(S, pts, n, outD, outM);
 }
 
 // device math primitives, for bit-parity tests against the oracle
@@ -1072,6 +1146,13 @@ extern "C" __global__ void ft_math_kernel(int op, const float* __restrict__ x, c
             case 2: r = sqrtf(v); break;
             case 4: r = ft_sqrt_fast(v); break;
             case 5: r = ft_exp_fast<false>(v); break;
+            case 6: r = ft_glibc_expf<true>(v, ft_libm_tab_g); break;      // glibc restatements (ft_libm.h): FMA build ...
+            case 7: r = ft_glibc_expf<false>(v, ft_libm_tab_g); break;     // ... SSE2 build
+            case 8: r = ft_glibc_logf<true>(v, ft_libm_tab_g); break;
+            case 9: r = ft_glibc_logf<false>(v, ft_libm_tab_g); break;
+            case 10: r = ft_glibc_powf<true>(v, y[i], ft_libm_tab_g); break;
+            case 11: r = ft_glibc_powf<false>(v, y[i], ft_libm_tab_g); break;
+            case 12: r = ft_pow(v, y[i]); break;
             default: r = v / y[i]; break;
         }
         out[i] = r;
@@ -1127,21 +1208,30 @@ extern "C" __global__ void __launch_bounds__(256) ft_tonemap_max_kernel(const fl
     }
 }
 
-__device__ __forceinline__ uint32_t tonemap_pixel(const float* __restrict__ px, float mx, float gammaInv, uint32_t dither, uint32_t seed, uint32_t x, uint32_t y) {
+// MathF.Pow: math = 0 the fixed algorithm (ft_math.h), 1 / 2 glibc's powf, FMA / SSE2 build (ft_libm.h, tables in LDS at `tab`)
+__device__ __forceinline__ float ft_pow_m(float x, float g, int math, const ft_u64* tab) {
+    if (math == 0) return ft_pow(x, g);
+    return math == 1 ? ft_glibc_powf<true>(x, g, tab) : ft_glibc_powf<false>(x, g, tab);
+}
+__device__ __forceinline__ uint32_t tonemap_pixel(const float* __restrict__ px, float mx, float gammaInv, uint32_t dither, uint32_t seed, uint32_t x, uint32_t y,
+                                                  int math, const ft_u64* tab) {
     // fcolor / max |> gammaInverse gammaInv |> toColor rng  (Image.fs:47-49): R, G, B in the order the reference draws its noise
-    const float r = ft_pow(px[0] / mx, gammaInv), g = ft_pow(px[1] / mx, gammaInv), b = ft_pow(px[2] / mx, gammaInv);
+    const float r = ft_pow_m(px[0] / mx, gammaInv, math, tab), g = ft_pow_m(px[1] / mx, gammaInv, math, tab), b = ft_pow_m(px[2] / mx, gammaInv, math, tab);
     const float ur = dither ? ft_dither_u(x, y, 0u, seed) : 0.5f, ug = dither ? ft_dither_u(x, y, 1u, seed) : 0.5f, ub = dither ? ft_dither_u(x, y, 2u, seed) : 0.5f;
     return ft_to_byte(r, ur) | (ft_to_byte(g, ug) << 8) | (ft_to_byte(b, ub) << 16);
 }
 
 // pass 2, Color[X,Y] order: out[(x * Y + y) * 3 + {0,1,2}] = R, G, B  (the value of Image.toColors)
 extern "C" __global__ void __launch_bounds__(256) ft_tonemap_map_kernel(const float* __restrict__ frame, uint32_t X, uint32_t Y, const uint32_t* __restrict__ maxBits,
-                                                                       float gammaInv, uint32_t dither, uint32_t seed, unsigned char* __restrict__ out) {
+                                                                       float gammaInv, uint32_t dither, uint32_t seed, unsigned char* __restrict__ out, int math) {
+    __shared__ ft_u64 tab[FT_LIBM_TAB_DOUBLES];
+    if (threadIdx.x < FT_LIBM_TAB_DOUBLES) tab[threadIdx.x] = ft_libm_tab_g[threadIdx.x];
+    __syncthreads();
     const float mx = __uint_as_float(*maxBits);
     const unsigned long long n = (unsigned long long)X * Y;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t x = (uint32_t)(i / Y), y = (uint32_t)(i - (unsigned long long)x * Y);
-        const uint32_t c = tonemap_pixel(frame + 3ull * i, mx, gammaInv, dither, seed, x, y);
+        const uint32_t c = tonemap_pixel(frame + 3ull * i, mx, gammaInv, dither, seed, x, y, math, tab);
         unsigned char* o = out + 3ull * i;
         o[0] = (unsigned char)c; o[1] = (unsigned char)(c >> 8); o[2] = (unsigned char)(c >> 16);
     }
@@ -1152,14 +1242,17 @@ extern "C" __global__ void __launch_bounds__(256) ft_tonemap_map_kernel(const fl
 // y fastest (contiguous in the frame), turned in LDS and written with c fastest (contiguous in the bitmap).
 #define FT_TM_TILE 64
 extern "C" __global__ void __launch_bounds__(256) ft_tonemap_bmp_kernel(const float* __restrict__ frame, uint32_t X, uint32_t Y, const uint32_t* __restrict__ maxBits,
-                                                                       float gammaInv, uint32_t dither, uint32_t seed, unsigned char* __restrict__ out) {
+                                                                       float gammaInv, uint32_t dither, uint32_t seed, unsigned char* __restrict__ out, int math) {
     __shared__ uint32_t tile[FT_TM_TILE][FT_TM_TILE + 1];
+    __shared__ ft_u64 tab[FT_LIBM_TAB_DOUBLES];
+    if (threadIdx.x < FT_LIBM_TAB_DOUBLES) tab[threadIdx.x] = ft_libm_tab_g[threadIdx.x];
+    __syncthreads();
     const float mx = __uint_as_float(*maxBits);
     const uint32_t tilesY = (Y + FT_TM_TILE - 1) / FT_TM_TILE;
     const uint32_t x0 = (blockIdx.x / tilesY) * FT_TM_TILE, y0 = (blockIdx.x % tilesY) * FT_TM_TILE;
     for (uint32_t k = threadIdx.x; k < FT_TM_TILE * FT_TM_TILE; k += 256) {
         const uint32_t lx = k / FT_TM_TILE, ly = k % FT_TM_TILE, x = x0 + lx, y = y0 + ly;
-        if (x < X && y < Y) tile[lx][ly] = tonemap_pixel(frame + 3ull * ((unsigned long long)x * Y + y), mx, gammaInv, dither, seed, x, y);
+        if (x < X && y < Y) tile[lx][ly] = tonemap_pixel(frame + 3ull * ((unsigned long long)x * Y + y), mx, gammaInv, dither, seed, x, y, math, tab);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < FT_TM_TILE * FT_TM_TILE; k += 256) {
@@ -1321,6 +1414,15 @@ extern "C" int ft_debug_set_hsaco(const char* path) {
 extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, size_t ldsBytes, hipStream_t st) {
     const bool ext = a->ext != 0u;
     const unsigned v = a->S.fastPath;
+    if (a->math != 0u) {                // FT_OPT_MATH = glibc, scene with a unionSmooth
+        if (v == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+        else if (v == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+        else if (v == 2 && ext) hipLaunchKernelGGL(ft_trace_kernel_calls_ext_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+        else if (v == 2) hipLaunchKernelGGL(ft_trace_kernel_calls_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+        else if (ext) hipLaunchKernelGGL(ft_trace_kernel_ext_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+        else hipLaunchKernelGGL(ft_trace_kernel_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
+        return hipGetLastError();
+    }
 #ifdef FT_EXPERIMENT
     if (v == 1 && !ext && ft_exp_fn) {
         FtRenderArgs args = *a;
@@ -1337,9 +1439,46 @@ extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, si
     else hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     return hipGetLastError();
 }
-extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, const float* pts, long long n, float* outD, int* outM,
+extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, int math, const float* pts, long long n, float* outD, int* outM,
                                             unsigned blocks, size_t ldsBytes, hipStream_t st) {
-    hipLaunchKernelGGL(ft_eval_points_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *S, pts, n, outD, outM);
+    if (math) hipLaunchKernelGGL(ft_eval_points_kernel_libm, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *S, pts, n, outD, outM);
+    else hipLaunchKernelGGL(ft_eval_points_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *S, pts, n, outD, outM);
+    return hipGetLastError();
+}
+// checksums of the glibc restatements over whole ranges of float bit patterns (ft_selftest_libm): chunk c covers the 2^24 patterns from
+// lo + c * 2^24; sum of splitmix64((input bits << 32) | result bits), NaN results canonicalised — the host forms the same sums with the real libm
+__device__ __forceinline__ ft_u64 ft_splitmix64(ft_u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+extern "C" __global__ void __launch_bounds__(256) ft_libm_checksum_kernel(int op, int variant, float y, uint32_t lo, unsigned long long* __restrict__ sums) {
+    __shared__ ft_u64 tab[FT_LIBM_TAB_DOUBLES];
+    __shared__ unsigned long long part[4];
+    if (threadIdx.x < FT_LIBM_TAB_DOUBLES) tab[threadIdx.x] = ft_libm_tab_g[threadIdx.x];
+    __syncthreads();
+    // 64 blocks per chunk of 2^24 inputs: 2^18 per block, 2^10 per thread
+    const uint32_t chunk = blockIdx.x >> 6, sub = blockIdx.x & 63u;
+    const uint32_t base = lo + (chunk << 24) + (sub << 18);
+    ft_u64 acc = 0;
+    for (uint32_t k = threadIdx.x; k < (1u << 18); k += 256u) {
+        const uint32_t u = base + k;
+        const float x = __uint_as_float(u);
+        float r;
+        if (op == 0) r = variant == 1 ? ft_glibc_expf<true>(x, tab) : ft_glibc_expf<false>(x, tab);
+        else if (op == 1) r = variant == 1 ? ft_glibc_logf<true>(x, tab) : ft_glibc_logf<false>(x, tab);
+        else r = variant == 1 ? ft_glibc_powf<true>(x, y, tab) : ft_glibc_powf<false>(x, y, tab);
+        const uint32_t v = r != r ? 0x7fc00000u : __float_as_uint(r);
+        acc += ft_splitmix64(((ft_u64)u << 32) | v);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[chunk], part[0] + part[1] + part[2] + part[3]);
+}
+extern "C" hipError_t ft_launch_libm_checksum(int op, int variant, float y, uint32_t lo, uint32_t nChunks, unsigned long long* d_sums, hipStream_t st) {
+    hipLaunchKernelGGL(ft_libm_checksum_kernel, dim3(nChunks * 64u), dim3(256), 0, st, op, variant, y, lo, d_sums);
     return hipGetLastError();
 }
 extern "C" hipError_t ft_launch_math(int op, const float* x, const float* y, long long n, float* out, hipStream_t st) {
@@ -1359,7 +1498,7 @@ extern "C" hipError_t ft_launch_resolve(const float* planes, float* out, unsigne
     return hipGetLastError();
 }
 extern "C" hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_t* maxBits, float gammaInv, uint32_t dither, uint32_t seed,
-                                        int bmpOrder, unsigned char* out, unsigned numCUs, hipStream_t st) {
+                                        int bmpOrder, unsigned char* out, unsigned numCUs, int math, hipStream_t st) {
     const unsigned long long nFloats = 3ull * X * Y;
     hipError_t e = hipMemsetAsync(maxBits, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
@@ -1368,11 +1507,11 @@ extern "C" hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t
     hipLaunchKernelGGL(ft_tonemap_max_kernel, dim3((unsigned)(want < 1 ? 1 : (want < maxBlocks ? want : maxBlocks))), dim3(256), 0, st, frame, nFloats, maxBits);
     if (bmpOrder) {
         const unsigned tiles = ((X + FT_TM_TILE - 1) / FT_TM_TILE) * ((Y + FT_TM_TILE - 1) / FT_TM_TILE);
-        hipLaunchKernelGGL(ft_tonemap_bmp_kernel, dim3(tiles), dim3(256), 0, st, frame, X, Y, (const uint32_t*)maxBits, gammaInv, dither, seed, out);
+        hipLaunchKernelGGL(ft_tonemap_bmp_kernel, dim3(tiles), dim3(256), 0, st, frame, X, Y, (const uint32_t*)maxBits, gammaInv, dither, seed, out, math);
     } else {
         const unsigned long long wantP = ((unsigned long long)X * Y + 255ull) / 256ull;
         hipLaunchKernelGGL(ft_tonemap_map_kernel, dim3((unsigned)(wantP < maxBlocks * 4ull ? wantP : maxBlocks * 4ull)), dim3(256), 0, st, frame, X, Y,
-                           (const uint32_t*)maxBits, gammaInv, dither, seed, out);
+                           (const uint32_t*)maxBits, gammaInv, dither, seed, out, math);
     }
     return hipGetLastError();
 }
@@ -1388,7 +1527,13 @@ extern "C" hipError_t ft_debug_union_counters(unsigned long long out[12]) {
     return hipMemcpyToSymbol(HIP_SYMBOL(ft_union_dbg), zero, sizeof(zero));
 }
 #endif
-extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, size_t ldsBytes, int* blocksPerCU) {
+extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU) {
+    if (libm) {
+        const void* kl = fastPath == 1 ? (ext ? (const void*)ft_trace_kernel_smooth_spheres_ext_libm : (const void*)ft_trace_kernel_smooth_spheres_libm)
+                       : fastPath == 2 ? (ext ? (const void*)ft_trace_kernel_calls_ext_libm : (const void*)ft_trace_kernel_calls_libm)
+                                       : (ext ? (const void*)ft_trace_kernel_ext_libm : (const void*)ft_trace_kernel_libm);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, kl, FT_BLOCK, ldsBytes);
+    }
     const void* k = fastPath == 1 ? (ext ? (const void*)ft_trace_kernel_smooth_spheres_ext : (const void*)ft_trace_kernel_smooth_spheres)
                   : fastPath == 2 ? (ext ? (const void*)ft_trace_kernel_calls_ext : (const void*)ft_trace_kernel_calls)
                                   : (ext ? (const void*)ft_trace_kernel_ext : (const void*)ft_trace_kernel);

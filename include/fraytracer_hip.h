@@ -112,8 +112,19 @@ typedef enum ft_option {
     FT_OPT_REFILL_MIN = 1,        /* 1..64 (default 64): idle lanes a wave waits for before it takes new rays */
     FT_OPT_MAX_BLOCKS_PER_CU = 2, /* 0 (default) = the occupancy limit; 1..8 caps the resident workgroups per CU */
     FT_OPT_HOST_CHUNKS = 3,       /* 0 (default) = automatic; 1..16 column chunks of ft_render's host-output pipeline */
-    FT_OPT_HOST_PIN = 4           /* 1 (default): ft_render page-locks an unregistered destination for the call; 0: leaves it pageable */
+    FT_OPT_HOST_PIN = 4,          /* 1 (default): ft_render page-locks an unregistered destination for the call; 0: leaves it pageable */
+    FT_OPT_MATH = 6               /* ft_math_mode (below); default FT_MATH_FIXED */
 } ft_option;
+/* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's
+ * expf / logf / powf under .NET: platform arithmetic, not one fixed function.
+ *   FT_MATH_FIXED       one fixed algorithm per function (IEEE + - * / fma only): the same bits on every machine; <= 0.93 ulp (exp),
+ *                       < 0.51 ulp (log), correctly rounded pow except at ~1e-7 of the operands.
+ *   FT_MATH_GLIBC_FMA   glibc 2.35's expf / logf / powf as its x86-64 FMA build computes them (`__expf_fma` ...: the variant glibc's ifunc
+ *                       selects on every CPU with FMA and AVX2) — bit for bit what the reference's CPU path returns on such a Linux host.
+ *   FT_MATH_GLIBC_SSE2  the same functions as glibc's SSE2 build rounds them (x86-64 CPUs without FMA / AVX2).
+ * Both glibc modes are restatements running on the GPU (csrc/ft_libm.h), proved against the running libm over all 2^32 inputs
+ * (ft_selftest_libm).  Scenes without a unionSmooth trace identically in every mode. */
+typedef enum ft_math_mode { FT_MATH_FIXED = 0, FT_MATH_GLIBC_FMA = 1, FT_MATH_GLIBC_SSE2 = 2 } ft_math_mode;
 int ft_ctx_set_option(ft_ctx* ctx, int32_t option, int32_t value);
 int ft_ctx_get_option(const ft_ctx* ctx, int32_t option, int32_t* value);
 
@@ -238,6 +249,12 @@ int ft_scene_grid_dump(const ft_scene*, int32_t g, uint32_t* cell_start, float* 
 /* math primitives of the device path, evaluated on the GPU: op 0 exp, 1 log, 2 sqrt, 3 a/b, 4 fast sqrt, 5 fast exp
  * (y = second operand, may be NULL otherwise).  Used by tests/test_math_parity.py. */
 int ft_math_eval(ft_ctx*, int32_t op, const float* x, const float* y, int64_t n, float* out);
+/* further ops of ft_math_eval: 6 / 7 glibc expf (FMA / SSE2 build), 8 / 9 glibc logf, 10 / 11 glibc powf(x, y), 12 the fixed pow(x, y).
+ * ft_selftest_libm: checksums of the device restatement of glibc's expf (op 0), logf (1) or powf(x, y) (2) in `variant`
+ * (FT_MATH_GLIBC_FMA / FT_MATH_GLIBC_SSE2) over n_chunks x 2^24 consecutive float bit patterns from lo_bits:
+ * sums[c] = sum over the chunk of splitmix64((input bits << 32) | result bits) mod 2^64, every NaN result taken as 0x7fc00000.  A test forms
+ * the same sums with the libm of the machine it runs on (256 chunks = every float). */
+int ft_selftest_libm(ft_ctx*, int32_t op, int32_t variant, float y, uint32_t lo_bits, int32_t n_chunks, uint64_t* sums);
 /* Exhaustive check, on the GPU, of the fast sqrt / exp forms used inside the smooth-union loop against
  * the exact forms, over EVERY float of the ranges they are used on; mismatches[0] = sqrt (both the five-instruction
  * form and the four-instruction form that runs with output modifiers enabled), [1] = exp (ldexp form, [-2.9e6, 88]),

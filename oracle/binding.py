@@ -67,6 +67,8 @@ def _load():
         "orc_spectral_table": (C.c_int, [C.c_int, C.c_void_p]), "orc_glass_hash": (C.c_uint32, [C.c_uint32, C.c_uint32]),
         "orc_fresnel": (None, [C.c_float, C.c_float, f3, f3, C.c_void_p]),
         "orc_powf": (C.c_float, [C.c_float, C.c_float]),
+        "orc_libm_checksums": (None, [C.c_int, C.c_float, C.c_uint32, C.c_int, C.c_void_p, C.c_int]),
+        "orc_libm_array": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
         "orc_tone_map": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint32, C.c_int, C.c_void_p]),
         "orc_pixel_ray": (None, [f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f3]),
     }
@@ -263,3 +265,17 @@ def tone_map(image, gamma=2.2, seed=None, bmp_order=False):
 
 def powf(x, g):
     return lib.orc_powf(x, g)
+
+
+def libm_checksums(op, y=0.0, lo_bits=0, n_chunks=256, nthreads=8):
+    """this machine's expf (op 0) / logf (1) / powf(x, y) (2): one checksum per 2^24 consecutive float bit patterns (orc_libm_checksums)"""
+    sums = np.zeros(n_chunks, np.uint64)
+    lib.orc_libm_checksums(int(op), float(y), int(lo_bits), int(n_chunks), sums.ctypes.data_as(C.c_void_p), int(nthreads))
+    return sums
+
+
+def libm_array(op, x, y=None):
+    x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+    yy = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    lib.orc_libm_array(int(op), x.ctypes.data_as(C.c_void_p), yy.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), x.size)
+    return out

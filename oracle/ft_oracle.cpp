@@ -917,6 +917,43 @@ void orc_reset(void) {
 }
 void orc_set_libm(int on) { g_use_libm = on != 0; }
 
+// The C runtime's expf (op 0) / logf (1) / powf(x, y) (2) of THIS machine over chunks of 2^24 consecutive float bit patterns from lo:
+// sums[c] = sum of splitmix64((input bits << 32) | result bits) mod 2^64, every NaN result taken as 0x7fc00000.  The product's device
+// restatement of glibc forms the same sums on the GPU (ft_selftest_libm); equal sums over all 256 chunks = equal on every float.
+static uint64_t orc_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void orc_libm_checksums(int op, float y, uint32_t lo, int n_chunks, uint64_t* sums, int nthreads) {
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int c = next.fetch_add(1);
+            if (c >= n_chunks) return;
+            uint64_t acc = 0;
+            const uint32_t base = lo + ((uint32_t)c << 24);
+            for (uint32_t k = 0; k < (1u << 24); ++k) {
+                const uint32_t u = base + k;
+                float x; memcpy(&x, &u, 4);
+                volatile float xv = x;                               // keep the call: no constant folding, no builtin expansion
+                const float r = op == 0 ? expf(xv) : (op == 1 ? logf(xv) : powf(xv, y));
+                uint32_t v; memcpy(&v, &r, 4);
+                if (r != r) v = 0x7fc00000u;
+                acc += orc_splitmix64(((uint64_t)u << 32) | v);
+            }
+            sums[c] = acc;
+        }
+    };
+    std::vector<std::thread> ts;
+    for (int t = 0; t < std::max(1, nthreads); ++t) ts.emplace_back(work);
+    for (auto& t : ts) t.join();
+}
+void orc_libm_array(int op, const float* x, const float* y, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) { volatile float xv = x[i]; out[i] = op == 0 ? expf(xv) : (op == 1 ? logf(xv) : powf(xv, y[i])); }
+}
+
 float orc_expf(float x) { return orc_expf_impl(x); }
 float orc_logf(float x) { return orc_logf_impl(x); }
 float orc_sqrtf(float x) { return sqrtf(x); }
@@ -1238,6 +1275,7 @@ static double orc_exp_double(double x) {                             // fdlibm e
     return out;
 }
 static float orc_powf_impl(float x, float g) {                       // MathF.Pow(x, g), FColor.fs:52-54
+    if (g_use_libm) return powf(x, g);                               // orc_set_libm(1): the C runtime's powf, as under .NET on this machine
     if (g == 0.0f) return 1.0f;
     if (x != x || g != g) return NAN;
     if (g == 1.0f) return x;

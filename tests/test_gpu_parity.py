@@ -107,6 +107,108 @@ def test_smooth_union_guard_fallbacks(gpu, oracle):
     assert np.isinf(d).any() and np.isnan(d).any()
 
 
+@pytest.fixture
+def glibc_mode(gpu, oracle):
+    """FT_OPT_MATH = the glibc build this host's libm resolves to, with the oracle switched to the C runtime's expf / logf / powf"""
+    variant = ft.glibc_build_of_this_host()
+    gpu.set_option("math", variant)
+    oracle.lib.orc_set_libm(1)
+    try:
+        yield variant
+    finally:
+        oracle.lib.orc_set_libm(0)
+        gpu.set_option("math", 0)
+
+
+def test_glibc_restatement_on_the_device(gpu, oracle):
+    """ft_selftest_libm: the device restatement of glibc's expf / logf / powf(x, 1/2.2f) over EVERY float (256 chunks of 2^24 bit
+    patterns, one checksum each) against the C runtime of the machine this test runs on — equal sums chunk by chunk.  The variant
+    is the build that libm resolves to here (FMA on every MI355X host); the other variant must NOT match for expf (the two builds
+    differ on a handful of inputs), which shows the checksum can tell them apart."""
+    import os
+    variant = ft.glibc_build_of_this_host()
+    nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+    y = float(np.float32(1.0) / np.float32(2.2))
+    for op, yy in ((0, 0.0), (1, 0.0), (2, y)):
+        want = oracle.libm_checksums(op, yy, 0, 256, nthreads)
+        got = gpu.selftest_libm(op, variant, yy, 0, 256)
+        bad = np.nonzero(want != got)[0]
+        assert bad.size == 0, (op, variant, bad[:8])
+        if op == 0:
+            other = gpu.selftest_libm(op, 3 - variant, yy, 0, 256)
+            assert 0 < int((other != want).sum()) <= 8
+    # array entry points of the same functions (ft_math_eval ops 6 .. 11), special values included
+    x = np.concatenate([np.random.default_rng(2).normal(0, 30, 20000), [0, -0.0, np.inf, -np.inf, np.nan, 88.7, 88.8, -103.9, -104.1, 1e-40, 1.0]]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        assert_bit_equal(gpu.math_eval(5 + variant, x), oracle.libm_array(0, x), "expf")
+        e, o = gpu.math_eval(7 + variant, x), oracle.libm_array(1, x)
+        assert np.array_equal(np.isnan(e), np.isnan(o)); assert_bit_equal(np.nan_to_num(e, nan=0.0), np.nan_to_num(o, nan=0.0), "logf")
+        yv = np.random.default_rng(3).normal(0, 3, x.size).astype(np.float32)
+        e, o = gpu.math_eval(9 + variant, x, yv), oracle.libm_array(2, x, yv)
+        assert np.array_equal(np.isnan(e), np.isnan(o)); assert_bit_equal(np.nan_to_num(e, nan=0.0), np.nan_to_num(o, nan=0.0), "powf")
+
+
+def test_glibc_math_mode_renders_what_the_oracle_renders_with_libm(gpu, oracle, glibc_mode):
+    """FT_OPT_MATH = glibc: SdfForm.unionSmooth's MathF.Exp / MathF.Log (SdfForm.fs:80,82) as this host's C runtime computes them.
+    The oracle calls the real expf / logf (orc_set_libm); the kernels run the restatement: bit-exact images and exact counters for
+    the lean kernel (C3), its EXTENSION build, the general kernel (smooth unions next to every other combinator), the call-capable
+    kernel and single distances incl. the far / centre / non-finite points.  In the default mode the same frames differ."""
+    cam = syn.default_camera()
+    scene, _ = syn.config3(n=256, size=256)
+    ds, os_ = both(gpu, oracle, scene)
+    assert ds.info()["fast_path"] == 1
+    g, gst = ds.render(EPS, LEN, ft.ImageSize(256, 256), cam)
+    o, ocnt = os_.render(EPS, LEN, 256, 256, cam.as_array())
+    assert_bit_equal(g, o, "C3 256^2 in glibc mode")
+    check_counts(gst, ocnt)
+    gpu.set_option("math", 0)
+    g0, _ = ds.render(EPS, LEN, ft.ImageSize(256, 256), cam)
+    gpu.set_option("math", glibc_mode)
+    assert not np.array_equal(g0.view(np.uint32), g.view(np.uint32))           # the two arithmetics are different functions
+    g4, _ = ds.render(EPS, LEN, ft.ImageSize(96, 96), cam, spp=4, ao_samples=3, ao_radius=0.5)
+    o4, _ = os_.render(EPS, LEN, 96, 96, cam.as_array(), spp=4, ao_samples=3, ao_radius=0.5)
+    assert_bit_equal(g4, o4, "C3 EXTENSION build in glibc mode")
+    for name, sc in (("mixed nested", syn.mixed_nested()[0]), ("combinator zoo", syn.combinator_zoo()[0]), ("crowd (call children)", syn.combinator_crowd(n=60)[0])):
+        ds2, os2 = both(gpu, oracle, sc)
+        g, gst = ds2.render(EPS, LEN, ft.ImageSize(96, 96), cam)
+        o, ocnt = os2.render(EPS, LEN, 96, 96, cam.as_array())
+        assert_bit_equal(g, o, name + " in glibc mode")
+        check_counts(gst, ocnt)
+    # single evaluations, guard regimes of the sphere run included
+    scene37, _ = syn.config3(n=37)
+    ds3, os3 = both(gpu, oracle, scene37)
+    O = oracle.Oracle()
+    form = O.object_form(os3.object)
+    rng = np.random.default_rng(5)
+    centre = np.array(scene37.Object.kids[1].kids[0].args[0], np.float32)
+    pts = np.concatenate([rng.uniform(-6, 6, (4000, 3)), rng.uniform(-60, 60, (4000, 3)), rng.uniform(-3000, 3000, (2000, 3)),
+                          [centre, centre + np.float32(1e-30)], [[1e18, 0, 0], [3e38, 3e38, 3e38], [np.inf, 0, 0], [np.nan, 0, 0], [0, 0, 25.9]]]).astype(np.float32)
+    d, _ = ds3.eval_distance(pts)
+    with np.errstate(all="ignore"):
+        want = O.form_distance(form, pts)
+    assert np.array_equal(np.isnan(d), np.isnan(want))
+    assert_bit_equal(np.nan_to_num(d, nan=0.0), np.nan_to_num(want, nan=0.0), "smooth-union distances in glibc mode")
+    # a scene without a unionSmooth has no exponential: the option changes nothing (and no *_libm kernel is launched)
+    c2, _ = syn.config2(seed=4, size=64)
+    ds4 = gpu.scene(c2)
+    a, _ = ds4.render(EPS, LEN, ft.ImageSize(64, 64), cam)
+    gpu.set_option("math", 0)
+    b, _ = ds4.render(EPS, LEN, ft.ImageSize(64, 64), cam)
+    assert_bit_equal(a, b, "C2 is the same in every math mode")
+
+
+def test_glibc_math_mode_tone_map(gpu, oracle, glibc_mode):
+    """FColor.gammaInverse's MathF.Pow (FColor.fs:50-55) as this host's powf: bytes of the device tone map = the oracle's with libm"""
+    rng = np.random.default_rng(8)
+    img = (rng.random((120, 77, 3)) ** 3 * 4.0).astype(np.float32)
+    img[3, 2] = (np.nan, 0.0, -1.0); img[9, 0] = 0.0; img[10, 5] = (1e-30, 1e-38, 1e-44)
+    for gamma in (2.2, 1.8, 1.0):
+        for seed, bmp in ((None, False), (19, True)):
+            want, wmx = oracle.tone_map(img, gamma=gamma, seed=seed, bmp_order=bmp)
+            got = ft.Image.toColors(gamma, seed, img, gpu, bmp_order=bmp)
+            assert np.array_equal(got, want), (gamma, seed, bmp)
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
