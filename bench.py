@@ -298,6 +298,38 @@ def main():
         cst = cds.collect_stats()
         console = {"stats": cst, "frame": cbuf, "scene": cscene, "W": CW}
 
+    # FT_OPT_MATH = glibc: the same K frames with MathF.Exp / Log as this host's C runtime computes them (glibc's expf / logf restated on
+    # the GPU, csrc/ft_libm.h) — the arithmetic the reference's CPU path would use on this very machine.  Checked further down against the
+    # oracle switched to the real libm; `value` stays the default (fixed) arithmetic.
+    libm = None
+    if world == 1 and pipe is None and not args.no_spp4:
+        variant = ft.glibc_build_of_this_host()
+        fixed_frame = slab.clone()
+        dev.set_option("math", variant)
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr())
+        torch.cuda.synchronize(); ds.collect_stats()
+        for _ in range(args.steps):
+            ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr())
+        torch.cuda.synchronize()
+        sl_ = ds.collect_stats()
+        dev.set_option("math", 0)
+        lib_frame = slab.clone()
+        a64, b64 = fixed_frame.double(), lib_frame.double()
+        rel = ((a64 - b64).abs() / b64.abs().clamp_min(1e-3)).amax(dim=2)
+        same = (fixed_frame.view(torch.int32) == lib_frame.view(torch.int32)).all(dim=2)
+        rays_l = (sl_["rays_primary"] + sl_["rays_shadow"]) / args.steps
+        kms_l = sl_["kernel_ms"] / args.steps
+        libm = {"value": round(rays_l / kms_l / 1e3, 1), "unit": "Mrays/s", "kernel_ms": round(kms_l, 3),
+                "kernel": "ft_trace_kernel_smooth_spheres_libm", "glibc_build": "FMA" if variant == 1 else "SSE2",
+                "fixed_vs_glibc": {"pixels_identical": round(float(same.double().mean()), 4), "pixels_over_1e-4_relative": round(float((rel > 1e-4).double().mean()), 6),
+                                   "max_relative": float(rel.max())},
+                "frame": lib_frame,
+                "note": "MathF.Exp / Log = glibc 2.35 expf / logf, restated in double precision on the GPU and proved equal to this host's libm on "
+                        "every float (tests: test_glibc_restatement_on_the_device); fixed_vs_glibc is the distance the default arithmetic keeps "
+                        "from it on this frame — what DESIGN.md section 2 calls the unpinnable residual"}
+        slab.copy_(fixed_frame)
+        del fixed_frame, a64, b64
+
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"]],
                        dtype=torch.int64, device="cuda")
@@ -378,6 +410,8 @@ def main():
             out["config"]["pixels_compared_with_oracle"] = check["pixels"]
             if console is not None:
                 out["config"]["program_fs_scene"] = program_fs_block(console, cam, args.steps)
+            if libm is not None:
+                out["config"]["glibc_math_mode"] = libm_block(libm, scene, cam, W, H)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -412,6 +446,24 @@ def program_fs_block(console, cam, steps):
                          "primitive_evals_per_eval": round(sum(cnt["prim"]) / max(1, cnt["root_evals"]), 2),
                          "note": "the reference scans a cell's whole candidate list (13 flops per candidate); the kernel leaves the sorted "
                                  "list at the first failing LowerBound test (exact), so it executes fewer than the priced operations"}}
+
+
+def libm_block(libm, scene, cam, W, H):
+    """the glibc-mode frame against the oracle calling this host's real expf / logf (orc_set_libm) on a column sample"""
+    import numpy as np
+    from oracle import binding as ob
+    frame = libm.pop("frame")
+    xstep = max(1, W // 64)
+    osc = ob.Oracle().scene(scene)
+    ob.lib.orc_set_libm(1)
+    try:
+        img, _ = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=host_cpu_share())
+    finally:
+        ob.lib.orc_set_libm(0)
+    got = frame[::xstep].cpu().numpy()
+    libm["max_abs_delta_vs_oracle_with_libm"] = float(np.max(np.abs(got.astype(np.float64) - img.astype(np.float64))))
+    libm["pixels_compared_with_oracle"] = int(img.shape[0] * img.shape[1])
+    return libm
 
 
 def host_cpu_share():
