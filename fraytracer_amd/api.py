@@ -368,7 +368,8 @@ class Device:
         check(lib.ft_ctx_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
     OPTIONS = {"refill_min": _lib.FT_OPT_REFILL_MIN, "max_blocks_per_cu": _lib.FT_OPT_MAX_BLOCKS_PER_CU,
-               "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN, "math": _lib.FT_OPT_MATH}
+               "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN, "math": _lib.FT_OPT_MATH,
+               "tail_k": _lib.FT_OPT_TAIL_K}
 
     def set_option(self, name, value):
         """ft_ctx_set_option: per-context switches (the library reads no environment variables)"""

@@ -57,6 +57,7 @@ struct ft_ctx {
     int optHostChunks = 0;                                 // 0: automatic (4 for frames >= 16 MB)
     int optHostPin = 1;                                    // page-lock an unregistered ft_render destination for the call
     int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
+    int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
 };
 
 struct ft_scene {
@@ -196,10 +197,17 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 
 // statistics header, per-lane value slots (distance + material index), the staged constant-pool prefix; the *_libm kernels keep glibc's
 // tables behind that, 8-byte aligned (kernels.hip ft_libm_lds_offset)
+// (kernels.hip ft_libm_lds_offset); the lean kernel keeps one row of FT_COOP_SEG floats per wave behind everything (16-byte aligned) for
+// the latency mode (kernels.hip ft_coop_lds_offset)
+#define FT_COOP_SEG_FLOATS 256
 size_t ldsBytes(const ft_scene* s, bool libm = false) {
-    const size_t floats = (size_t)FT_LDS_HDR_FLOATS + (size_t)s->dev.nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
-    return libm ? ((floats + 1) & ~(size_t)1) * 4 + (size_t)FT_LIBM_TAB_DOUBLES * 8 : floats * 4;
+    size_t floats = (size_t)FT_LDS_HDR_FLOATS + (size_t)s->dev.nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
+    if (libm) floats = ((floats + 1) & ~(size_t)1) + (size_t)FT_LIBM_TAB_DOUBLES * 2;
+    if (s->dev.fastPath == 1u) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
+    return floats * 4;
 }
+// Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
+constexpr int FT_TAIL_K_LEAN = 8, FT_TAIL_K_GENERAL = 4;
 // does this launch take the glibc build of the kernels?
 bool libmLaunch(const ft_ctx* c, const ft_scene* s) { return c->optMath != FT_MATH_FIXED && s->usesExpLog; }
 
@@ -250,6 +258,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     // glass config 39.1 / 31.5 / 27.3, and even the VALU-bound C3 kernel 61.0 / 66.5 / 60.3: rays that start together stay in
     // step (march, the four normal probes, shadow rays), so a wave's lanes share lookup cells, list positions and branches.
     a.refillMin = (uint32_t)c->optRefillMin;               // 64 unless FT_OPT_REFILL_MIN says otherwise (experiments)
+    a.tailK = (uint32_t)(c->optTailK >= 0 ? c->optTailK : (s->dev.fastPath == 1u ? FT_TAIL_K_LEAN : FT_TAIL_K_GENERAL));
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
@@ -302,6 +311,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_MAX_BLOCKS_PER_CU: if (value < 0 || value > 8) return setErr(FT_ERR_INVALID, "FT_OPT_MAX_BLOCKS_PER_CU: 0 (no cap) .. 8"); c->optMaxBlocksPerCU = value; return FT_OK;
     case FT_OPT_HOST_CHUNKS: if (value < 0 || value > 16) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_CHUNKS: 0 (automatic) .. 16"); c->optHostChunks = value; return FT_OK;
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
+    case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
     case FT_OPT_MATH:
         if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
         c->optMath = value; return FT_OK;
@@ -316,6 +326,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_HOST_CHUNKS: *value = c->optHostChunks; return FT_OK;
     case FT_OPT_HOST_PIN: *value = c->optHostPin; return FT_OK;
     case FT_OPT_MATH: *value = c->optMath; return FT_OK;
+    case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
 }
@@ -565,7 +576,7 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
         st->hits_primary = h.hits_primary; st->hits_shadow = h.hits_shadow; st->sdf_evals = h.sdf_evals;
         st->flags = h.flags; st->kernel_ms = (float)ms; st->wave_evals = h.wave_evals;
         st->shader_mhz = h.clk_ref ? (float)((double)h.clk_shader / (double)h.clk_ref * 100.0) : 0.0f;   // s_memrealtime: 100 MHz
-        st->reserved2 = 0.0f;
+        st->tail_fraction = h.sdf_evals ? (float)((double)h.coop_evals / (double)h.sdf_evals) : 0.0f;
         st->reserved = 0.0f;
     }
     return FT_OK;

@@ -35,7 +35,7 @@ struct FtRenderArgs {
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
     uint32_t refillMin;       // idle lanes a wave waits for before it takes new rays (1 = refill at once; kernels.hip "Burst refill")
     uint32_t math;            // 0: the default kernels; 1: launch the *_libm build (FT_OPT_MATH = glibc and the scene has a unionSmooth)
-    uint32_t pad2;
+    uint32_t tailK;           // latency mode: a wave holding at most this many rays evaluates them one at a time with all 64 lanes (0 = off)
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move
     float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)

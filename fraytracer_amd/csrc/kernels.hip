@@ -480,7 +480,7 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
 
 // the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
-template <bool WITH_UNION, bool CALLS, int MATH>
+template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
                                         uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk);
 
@@ -552,7 +552,77 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
 // word s*FT_BLOCK + t: conflict-free).  Returns scene.Object.Form.Distance(p) and the material
 // the reference's material closure would pick at p.
 // ------------------------------------------------------------------------------------------------
-template <bool WITH_UNION, bool CALLS, int MATH>
+// Latency mode (see "Latency (tail) mode" below): the grid union of ONE query point, the same in all 64 lanes.  Items.[0] is evaluated by
+// every lane (SdfForm.fs:26).  Then, 64 candidates at a time, lane j loads record j of the cell's list and computes the right-hand sides of
+// the two pruning tests (:30 LowerBound - distanceToCenter, :31 getMinDistance) — they do not depend on the running minimum — and the wave
+// replays the reference's loop IN LIST ORDER over the candidates that can still pass (those that pass against the minimum the chunk starts
+// with: the minimum only falls): it broadcasts the candidate's two values, takes :30 and :31 against the current minimum and, where the
+// reference would call the candidate's Distance (:33), evaluates it — in every lane, on the same point, through the same code as the
+// one-ray-per-lane walk (primitive, slot, or sub-program) — and applies Min / the strict '<' of the material pick (SdfObject.fs:41-43).
+// Same tests, same order, same evaluations, same values: the result and the raised flags are those of eval_union / eval_union_prims.
+template <bool FQ, bool CALLS, int MATH>
+__device__ __forceinline__ void eval_union_coop(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
+                                                float* __restrict__ sd, uint32_t* __restrict__ sl, const float* __restrict__ ldsC,
+                                                bool fastOk, bool nearOk, float& outD, uint32_t& outLeaf) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
+    const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
+    const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
+    const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
+    const uint32_t cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g.cellBase + (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz)));
+    cfp ctr = as_const(S.cellCenters) + 3u * cell;
+    const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
+    const uint32_t FT_CONST* cellStart = as_const(S.cellStart);
+    const FtItemRec FT_CONST* items = as_const(S.items);
+    cfp consts = as_const(S.consts);
+    const uint32_t first = cellStart[cell], end = cellStart[cell + 1];
+
+    // evaluate one candidate in every lane (typeData / mat are wave-uniform)
+    auto evaluate = [&](uint32_t typeData, uint32_t mat, float& d, uint32_t& l) {
+        const uint32_t type = typeData & 15u, data = typeData >> 4;
+        if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
+        else if (CALLS && type == FT_PR_CALL) {
+            const uint32_t FT_CONST* cr = reinterpret_cast<const uint32_t FT_CONST*>(consts + data);   // (first instr, end instr, slot)
+            const uint32_t slot = cr[2];
+            ft_exec<false, false, MATH>(S, cr[0], cr[1], p, sd, sl, ldsC, fastOk, nearOk);
+            d = sd[slot * FT_BLOCK]; l = sl[slot * FT_BLOCK];
+        }
+        else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p); l = mat; }
+    };
+
+    float mn; uint32_t leaf;
+    {
+        const ItemRegs r0 = ld_item_at(items, first);                                   // Items.[0]: unconditional (:26)
+        evaluate((uint32_t)__builtin_amdgcn_readfirstlane((int)r0.b.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)r0.b.z), mn, leaf);
+    }
+    bool done = false;
+    for (uint32_t base = first + 1u; base < end && !done; base += 64u) {
+        const uint32_t idx = base + lane;
+        const bool have = idx < end;
+        const ItemRegs r = ld_item_at(items, have ? idx : end - 1u);
+        const float lb = r.a.x - distanceToCenter;                                      // :30 right-hand side
+        const float md = ft_dist<FQ>(mk3(r.a.y, r.a.z, r.a.w), p) - __uint_as_float(r.b.x);   // :31 getMinDistance
+        unsigned long long m = __ballot(have && mn > lb && mn > md);
+        while (m != 0ull) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const float lbj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), j));
+            const float mdj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(md), j));
+            // :30 is monotonic along the sorted list: once it fails it fails for every later candidate (see eval_union_prims)
+            if (__ballot(mn > lbj) == 0ull) { done = true; break; }
+            if (__ballot(mn > mdj) == 0ull) continue;                                   // :31
+            float d; uint32_t l;
+            evaluate((uint32_t)__builtin_amdgcn_readlane((int)r.b.y, j), (uint32_t)__builtin_amdgcn_readlane((int)r.b.z, j), d, l);
+            if (d < mn) leaf = l;                                                       // SdfObject.fs:41-43
+            mn = ft_min(mn, d);                                                         // SdfForm.fs:33
+        }
+        // a candidate of this chunk that fails :30 against the minimum the chunk ends with: every later one fails too
+        if (!done && __ballot(have && !(mn > lb)) != 0ull) done = true;
+    }
+    outD = mn; outLeaf = leaf;
+}
+
+template <bool WITH_UNION, bool CALLS, int MATH, bool COOP>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
                                         uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk) {
     cfp consts = as_const(S.consts);
@@ -612,6 +682,10 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
         case FT_OP_UNION: {
             if constexpr (WITH_UNION) {
                 float d; uint32_t l;
+                if constexpr (COOP) {                                  // latency mode: one point, candidates across the lanes
+                    if (fastOk && S.fastQ) eval_union_coop<true, CALLS, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                    else eval_union_coop<false, CALLS, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                } else
                 if constexpr (CALLS) {                                 // scenes with sub-program children (FtSceneDev.fastPath == 2)
                     if (fastOk && S.fastQ) eval_union<true, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                     else eval_union<false, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
@@ -634,6 +708,18 @@ __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* 
     const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
     const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
     ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
+    outD = sd[0];
+    outLeaf = sl[0];
+}
+
+// latency mode: the same program on one point p that all 64 lanes share; only the grid union is spread over the lanes (eval_union_coop),
+// every other instruction is computed redundantly by every lane
+template <bool CALLS, int MATH>
+__device__ __forceinline__ void ft_eval_coop(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
+                                             const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
+    const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
+    const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
+    ft_exec<true, CALLS, MATH, true>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -678,6 +764,90 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
                     acc = acc + ft_exp(in->f0 * (ft_distance(mk3(c[0], c[1], c[2]), p) - c[3]));
                 }
             }
+        }
+        else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log_m<MATH>(acc, S) * in->f0;
+        else leaf = in->aux;                                           // FT_OP_SETLEAF
+    }
+    outD = acc; outLeaf = leaf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Latency ("tail") mode: ONE ray per wave, its evaluation spread over the 64 lanes.
+//
+// A persistent wave pays one full scene evaluation per round however few of its lanes still hold a ray, and a kernel ends when its
+// longest rays end: once the job queue is empty those rays march on in nearly empty waves, one evaluation latency per step (C3: > 130
+// steps of ~30 000 cycles; 20 % of one rank's share of a frame at N = 8, ~40 % of the reference's own 1000^2 frame).  When a wave holds at
+// most FtRenderArgs.tailK rays, each of them is therefore evaluated cooperatively, one after the other, by all 64 lanes:
+//   * smooth union of spheres (lean kernel): lane j computes the exponentials of children 4j .. 4j+3 of a 256-child segment, the wave
+//     puts them in its LDS row and every lane adds them up IN CHILD ORDER (the reference's sequential f32 sum, SdfForm.fs:77-80) from
+//     broadcast reads: 4 exponentials + 256 dependent adds instead of 256 exponentials per lane;
+//   * grid union (general kernels): see eval_union_coop.
+// Evaluation has no side effects and every value is computed by the same operations as in the one-ray-per-lane path, so the result is
+// bit-identical by construction; it is also cheaper in wave instructions as soon as fewer than ~15 lanes hold a ray, so the mode is used
+// whenever a wave is that empty, not only at the end of a launch.
+// ------------------------------------------------------------------------------------------------
+#define FT_COOP_SEG 256                       // children per segment = floats of LDS per wave
+__device__ __forceinline__ uint32_t ft_coop_lds_offset(const FtSceneDev& S, bool libm) {
+    const uint32_t end = libm ? ft_libm_lds_offset(S) + 2u * FT_LIBM_TAB_DOUBLES : FT_LDS_HDR_FLOATS + 2u * S.nSlots * FT_BLOCK + S.nStage;
+    return (end + 3u) & ~3u;                  // 16-byte aligned: the row is written and read as float4
+}
+__device__ __forceinline__ f3 ft_readlane3(f3 v, int l) {
+    return mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), l)),
+               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), l)));
+}
+// one child's term exp(si * (|c - p| - r)) in the regime the point allows: 2 = near (exponent-add exp), 1 = far (ldexp exp), 0 = exact
+// forms — all three give the same bits wherever two of them are valid (ft_selftest_fastmath), so the choice is only about cost
+template <int MATH>
+__device__ __forceinline__ float ft_sphere_term(const float4 prm, const f3 p, const float si, const int regime, const FtSceneDev& S) {
+    const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
+    const float q = (dx * dx + dy * dy) + dz * dz;
+    if (MATH != 0) {
+        const float t = si * ((regime != 0 ? ft_sq<true>(q) : sqrtf(q)) - prm.w);
+        return S.mathFma ? ft_glibc_expf<true>(t, ft_libm_tab(S)) : ft_glibc_expf<false>(t, ft_libm_tab(S));
+    }
+    if (regime == 2) return ft_exp_fast<true>(si * (ft_sq<true>(q) - prm.w));
+    if (regime == 1) return ft_exp_fast<false>(si * (ft_sq<true>(q) - prm.w));
+    return ft_exp(si * (sqrtf(q) - prm.w));
+}
+// p is the same in every lane; `row` = this wave's FT_COOP_SEG floats of LDS
+template <int MATH>
+__device__ __forceinline__ void ft_eval_smooth_spheres_coop(const FtSceneDev& S, const f3 p, const float* __restrict__ ldsC, float* __restrict__ row,
+                                                            float& outD, uint32_t& outLeaf) {
+    const uint32_t lane = threadIdx.x & 63u;
+    float acc = 0.0f;
+    uint32_t leaf = 0;
+    const bool fastOk = fast_point_ok(p);
+    const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
+    const int regime = nearOk ? 2 : (fastOk ? 1 : 0);
+    for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
+        const FtInstr FT_CONST* in = as_const(S.instr) + pc;
+        const uint32_t op = in->op;
+        if (op == FT_OP_SMOOTH_RUN) {
+            float sum = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
+            const uint32_t count = in->count;
+            const float si = in->f0;
+            for (uint32_t seg = 0; seg < count; seg += FT_COOP_SEG) {
+                const uint32_t n = count - seg < FT_COOP_SEG ? count - seg : FT_COOP_SEG;
+                const float* c = ldsC + in->data + 4u * (seg + 4u * lane);
+                float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (4u * lane + 0u < n) e.x = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c), p, si, regime, S);
+                if (4u * lane + 1u < n) e.y = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 4), p, si, regime, S);
+                if (4u * lane + 2u < n) e.z = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 8), p, si, regime, S);
+                if (4u * lane + 3u < n) e.w = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 12), p, si, regime, S);
+                *reinterpret_cast<float4*>(row + 4u * lane) = e;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t i = 0;
+                for (; i + 4u <= n; i += 4u) {                         // the reference's sum, child by child (SdfForm.fs:77-80)
+                    const float4 v = *reinterpret_cast<const float4*>(row + i);
+                    sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
+                }
+                for (; i < n; ++i) sum = sum + row[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                       // the row is rewritten by the next segment / evaluation
+            }
+            acc = sum;
         }
         else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log_m<MATH>(acc, S) * in->f0;
         else leaf = in->aux;                                           // FT_OP_SETLEAF
@@ -931,8 +1101,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     for (uint32_t k = 0; k < FT_LDS_STAT_ROWS; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
     __syncthreads();
 
+    float* coopRow = ft_lds + ft_coop_lds_offset(a.S, MATH != 0) + (tid >> 6) * FT_COOP_SEG;   // lean kernel: this wave's row of the latency mode
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
     uint32_t waveEvals = 0;                                            // evaluation rounds of this wave (lane-utilisation statistic)
+    uint32_t coopEvals = 0;                                            // evaluations done in latency mode (wave-uniform)
     bool exhausted = false;
     LaneState s;
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
@@ -973,7 +1145,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         const bool active = s.phase >= PH_MARCH;
         waveEvals += 1;
         FT_UDBG_T0(tRound);
-        if (active) {
+        auto query_point = [&]() {
             f3 q = s.o;
             if (s.phase >= PH_NX && s.phase <= PH_NC) {                // SdfForm.fs:106-115
                 const f3 base = s.o + s.dir * (-s.eps);                // Ray.get (-eps)
@@ -983,10 +1155,35 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 if (s.phase == PH_NY) q.y = base.y + h;
                 if (s.phase == PH_NZ) q.z = base.z + h;
             }
+            return q;
+        };
+        // ---- latency mode: at most tailK rays left in this wave -> each is evaluated by all 64 lanes together ("Latency (tail) mode") ----
+        const unsigned long long am = __ballot(active);
+        const bool coop = (uint32_t)__popcll(am) <= a.tailK;           // tailK = 0: never
+        float dCoop = 0.0f; uint32_t leafCoop = 0;
+        if (coop) {
+            const f3 qm = query_point();
+            unsigned long long m = am;
+            while (m != 0ull) {
+                const int L = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const f3 qL = ft_readlane3(qm, L);
+                float dL; uint32_t leafL;
+                if (VARIANT == 1) ft_eval_smooth_spheres_coop<MATH>(a.S, qL, ldsC, coopRow, dL, leafL);
+                else ft_eval_coop<VARIANT == 2, MATH>(a.S, qL, sd, sl, ldsC, dL, leafL);
+                if ((int)lane == L) { dCoop = dL; leafCoop = leafL; }
+                coopEvals += 1;
+            }
+        }
+        if (active) {
             float d; uint32_t leaf;
             FT_UDBG_T0(tEval);
-            if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf);
-            else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
+            if (coop) { d = dCoop; leaf = leafCoop; }
+            else {
+                const f3 q = query_point();
+                if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf);
+                else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
+            }
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
             ft_count(FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
@@ -1062,6 +1259,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         atomicAdd(&a.stats->rays_primary, pr);
         if (ex) atomicAdd(&a.stats->rays_ext, ex);
         atomicAdd(&a.stats->wave_evals, (unsigned long long)waveEvals);
+        if (coopEvals) atomicAdd(&a.stats->coop_evals, (unsigned long long)coopEvals);
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
         if (blockIdx.x == 0 && tid == 0) { atomicAdd(&a.stats->clk_shader, clock64() - clk0[0]); atomicAdd(&a.stats->clk_ref, wall_clock64() - clk0[1]); }
     }

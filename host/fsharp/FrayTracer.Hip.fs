@@ -27,7 +27,7 @@ type FtRenderParams =
 type FtStats =
     { RaysPrimary : uint64; RaysShadow : uint64; RaysExt : uint64; HitsPrimary : uint64; HitsShadow : uint64
       SdfEvals : uint64; Flags : uint64; KernelMs : float32; Reserved : float32; WaveEvals : uint64
-      ShaderMHz : float32; Reserved2 : float32 }
+      ShaderMHz : float32; TailFraction : float32 }
 
 /// ft_camera (48 B).  The reference's `Camera` (Camera.fs:16-22) is an ordinary F# record — a reference type with
 /// automatic layout, NOT a [<Struct>] — so it cannot cross P/Invoke by reference; its four vectors are copied into

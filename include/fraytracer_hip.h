@@ -91,7 +91,7 @@ typedef struct ft_stats {         /* filled per call; all counts are exact */
     uint64_t wave_evals;          /* wave-level evaluation rounds: sdf_evals / (64 * wave_evals) = lane utilisation */
     float shader_mhz;             /* shader clock the render kernel(s) of this call ran at: s_memtime ticks / s_memrealtime ticks
                                    * (constant 100 MHz) of one wave that lives as long as the kernel; 0 if unknown */
-    float reserved2;
+    float tail_fraction;          /* share of sdf_evals done in latency mode (one ray per wave, FT_OPT_TAIL_K) */
 } ft_stats;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -113,6 +113,8 @@ typedef enum ft_option {
     FT_OPT_MAX_BLOCKS_PER_CU = 2, /* 0 (default) = the occupancy limit; 1..8 caps the resident workgroups per CU */
     FT_OPT_HOST_CHUNKS = 3,       /* 0 (default) = automatic; 1..16 column chunks of ft_render's host-output pipeline */
     FT_OPT_HOST_PIN = 4,          /* 1 (default): ft_render page-locks an unregistered destination for the call; 0: leaves it pageable */
+    FT_OPT_TAIL_K = 5,            /* latency mode: a wave holding at most this many rays evaluates them one at a time with all 64 lanes;
+                                   * -1 (default) = the kernel's own threshold, 0 = off, 1..64 */
     FT_OPT_MATH = 6               /* ft_math_mode (below); default FT_MATH_FIXED */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's
