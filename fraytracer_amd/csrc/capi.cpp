@@ -207,7 +207,7 @@ size_t ldsBytes(const ft_scene* s, bool libm = false) {
     return floats * 4;
 }
 // Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
-constexpr int FT_TAIL_K_LEAN = 8, FT_TAIL_K_GENERAL = 4;
+constexpr int FT_TAIL_K_LEAN = 32, FT_TAIL_K_GENERAL = 2;
 // does this launch take the glibc build of the kernels?
 bool libmLaunch(const ft_ctx* c, const ft_scene* s) { return c->optMath != FT_MATH_FIXED && s->usesExpLog; }
 

@@ -778,9 +778,8 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
 // longest rays end: once the job queue is empty those rays march on in nearly empty waves, one evaluation latency per step (C3: > 130
 // steps of ~30 000 cycles; 20 % of one rank's share of a frame at N = 8, ~40 % of the reference's own 1000^2 frame).  When a wave holds at
 // most FtRenderArgs.tailK rays, each of them is therefore evaluated cooperatively, one after the other, by all 64 lanes:
-//   * smooth union of spheres (lean kernel): lane j computes the exponentials of children 4j .. 4j+3 of a 256-child segment, the wave
-//     puts them in its LDS row and every lane adds them up IN CHILD ORDER (the reference's sequential f32 sum, SdfForm.fs:77-80) from
-//     broadcast reads: 4 exponentials + 256 dependent adds instead of 256 exponentials per lane;
+//   * smooth union of spheres (lean kernel): ft_eval_smooth_spheres_packed — all of the wave's rays in one pass, 64 / rays lanes per ray,
+//     every ray's exponentials spread over its lanes and added up IN CHILD ORDER from the wave's LDS row (up to 32 rays per wave);
 //   * grid union (general kernels): see eval_union_coop.
 // Evaluation has no side effects and every value is computed by the same operations as in the one-ray-per-lane path, so the result is
 // bit-identical by construction; it is also cheaper in wave instructions as soon as fewer than ~15 lanes hold a ray, so the mode is used
@@ -809,16 +808,37 @@ __device__ __forceinline__ float ft_sphere_term(const float4 prm, const f3 p, co
     if (regime == 1) return ft_exp_fast<false>(si * (ft_sq<true>(q) - prm.w));
     return ft_exp(si * (sqrtf(q) - prm.w));
 }
-// p is the same in every lane; `row` = this wave's FT_COOP_SEG floats of LDS
+// The wave's rays — at most 32, `am` = the lanes that hold one, `q` = their query points — are evaluated by groups of g = 64 / (rays rounded
+// up to a power of two) lanes each: group G serves the G-th ray.  A segment is 4g children: lane k of a group computes the exponentials
+// of children 4k .. 4k+3 of the segment and stores them at its own float4 of the wave's LDS row — which makes the row, group by group,
+// the segment's terms in child order — and then every lane of the group adds the group's 4g terms to its running sum, first to last (the
+// reference's sequential f32 sum, SdfForm.fs:77-80).  One round costs ~(7000 / g + 400) wave instructions against ~6700 of the
+// one-ray-per-lane evaluation, whatever the number of rays: cheaper from 32 rays down, and 1 / 18 of the latency for a single ray.
 template <int MATH>
-__device__ __forceinline__ void ft_eval_smooth_spheres_coop(const FtSceneDev& S, const f3 p, const float* __restrict__ ldsC, float* __restrict__ row,
-                                                            float& outD, uint32_t& outLeaf) {
+__device__ __forceinline__ void ft_eval_smooth_spheres_packed(const FtSceneDev& S, const f3 q, const bool active, const unsigned long long am, const uint32_t nRays,
+                                                              const float* __restrict__ ldsC, float* __restrict__ row, float& outD, uint32_t& outLeaf) {
     const uint32_t lane = threadIdx.x & 63u;
-    float acc = 0.0f;
-    uint32_t leaf = 0;
-    const bool fastOk = fast_point_ok(p);
+    const uint32_t rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+    const uint32_t lg = nRays <= 1u ? 6u : 6u - (32u - (uint32_t)__builtin_clz(nRays - 1u));      // log2 of the group size: 64 >> ceil(log2 rays)
+    const uint32_t g = 1u << lg;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // the rays' query points, in rank order, through the row
+    if (active) { row[3u * rank] = q.x; row[3u * rank + 1u] = q.y; row[3u * rank + 2u] = q.z; }
+    wave_sync();
+    const uint32_t G = lane >> lg, k = lane & (g - 1u);
+    const bool valid = G < nRays;
+    const f3 p = valid ? mk3(row[3u * G], row[3u * G + 1u], row[3u * G + 2u]) : mk3(0.0f, 0.0f, 0.0f);     // lanes of unused groups: any harmless point
+    wave_sync();
+    const bool fastOk = fast_point_ok(p);                              // wave-uniform, over all the rays of the round (as in the one-ray-per-lane path)
     const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
     const int regime = nearOk ? 2 : (fastOk ? 1 : 0);
+    const float* mine = row + 4u * (lane & ~(g - 1u));                 // this group's 4g terms of the current segment
+    float acc = 0.0f;
+    uint32_t leaf = 0;
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr FT_CONST* in = as_const(S.instr) + pc;
         const uint32_t op = in->op;
@@ -826,33 +846,31 @@ __device__ __forceinline__ void ft_eval_smooth_spheres_coop(const FtSceneDev& S,
             float sum = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
             const uint32_t count = in->count;
             const float si = in->f0;
-            for (uint32_t seg = 0; seg < count; seg += FT_COOP_SEG) {
-                const uint32_t n = count - seg < FT_COOP_SEG ? count - seg : FT_COOP_SEG;
-                const float* c = ldsC + in->data + 4u * (seg + 4u * lane);
+            for (uint32_t seg = 0; seg < count; seg += 4u * g) {
+                const uint32_t nv = count - seg < 4u * g ? count - seg : 4u * g;       // children in this segment
+                const float* c = ldsC + in->data + 4u * (seg + 4u * k);
                 float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (4u * lane + 0u < n) e.x = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c), p, si, regime, S);
-                if (4u * lane + 1u < n) e.y = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 4), p, si, regime, S);
-                if (4u * lane + 2u < n) e.z = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 8), p, si, regime, S);
-                if (4u * lane + 3u < n) e.w = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 12), p, si, regime, S);
+                if (4u * k + 0u < nv) e.x = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c), p, si, regime, S);
+                if (4u * k + 1u < nv) e.y = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 4), p, si, regime, S);
+                if (4u * k + 2u < nv) e.z = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 8), p, si, regime, S);
+                if (4u * k + 3u < nv) e.w = ft_sphere_term<MATH>(*reinterpret_cast<const float4*>(c + 12), p, si, regime, S);
                 *reinterpret_cast<float4*>(row + 4u * lane) = e;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_sync();
                 uint32_t i = 0;
-                for (; i + 4u <= n; i += 4u) {                         // the reference's sum, child by child (SdfForm.fs:77-80)
-                    const float4 v = *reinterpret_cast<const float4*>(row + i);
+                for (; i + 4u <= nv; i += 4u) {                        // the reference's sum, child by child (SdfForm.fs:77-80)
+                    const float4 v = *reinterpret_cast<const float4*>(mine + i);
                     sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
                 }
-                for (; i < n; ++i) sum = sum + row[i];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();                       // the row is rewritten by the next segment / evaluation
+                for (; i < nv; ++i) sum = sum + mine[i];
+                wave_sync();                                           // the row is rewritten by the next segment / round
             }
             acc = sum;
         }
         else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log_m<MATH>(acc, S) * in->f0;
         else leaf = in->aux;                                           // FT_OP_SETLEAF
     }
-    outD = acc; outLeaf = leaf;
+    outD = __shfl(acc, (int)(rank << lg), 64);                         // the ray of rank r was served by group r = lanes r*g ...
+    outLeaf = leaf;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1161,18 +1179,22 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         const unsigned long long am = __ballot(active);
         const bool coop = (uint32_t)__popcll(am) <= a.tailK;           // tailK = 0: never
         float dCoop = 0.0f; uint32_t leafCoop = 0;
-        if (coop) {
+        if (coop && am != 0ull) {
             const f3 qm = query_point();
-            unsigned long long m = am;
-            while (m != 0ull) {
-                const int L = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                const f3 qL = ft_readlane3(qm, L);
-                float dL; uint32_t leafL;
-                if (VARIANT == 1) ft_eval_smooth_spheres_coop<MATH>(a.S, qL, ldsC, coopRow, dL, leafL);
-                else ft_eval_coop<VARIANT == 2, MATH>(a.S, qL, sd, sl, ldsC, dL, leafL);
-                if ((int)lane == L) { dCoop = dL; leafCoop = leafL; }
-                coopEvals += 1;
+            if (VARIANT == 1) {                                        // smooth union of spheres: all the rays at once, 64 / rays lanes each
+                ft_eval_smooth_spheres_packed<MATH>(a.S, qm, active, am, (uint32_t)__popcll(am), ldsC, coopRow, dCoop, leafCoop);
+                coopEvals += (uint32_t)__popcll(am);
+            } else {                                                   // general scenes: one ray after the other, all 64 lanes each
+                unsigned long long m = am;
+                while (m != 0ull) {
+                    const int L = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const f3 qL = ft_readlane3(qm, L);
+                    float dL; uint32_t leafL;
+                    ft_eval_coop<VARIANT == 2, MATH>(a.S, qL, sd, sl, ldsC, dL, leafL);
+                    if ((int)lane == L) { dCoop = dL; leafCoop = leafL; }
+                    coopEvals += 1;
+                }
             }
         }
         if (active) {
