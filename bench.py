@@ -52,22 +52,26 @@ def union_algorithmic_flops(cnt):
             + (30 + 12 + 2) * cnt["root_evals"] + 8 * cnt["march_steps"] + 20 * cnt["hits_primary"] + 25 * cnt["rays_shadow"])
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (separate
-    FETCH_SIZE / WRITE_SIZE runs of this same command, tools/profile.sh).  FETCH_SIZE is doubled as the
-    MI355X guide prescribes for gfx950; both counters are in KiB.  None if no profile is committed."""
+def profile_figures(build_src, kernel):
+    """PMC figures of `kernel` from a COMMITTED rocprofv3 summary (separate --pmc passes of tools/profile.sh / profile_scene.sh) — but only
+    from a summary that was captured on the very sources the running library was built from: tools/summarize_prof.py stamps every
+    summary with ft_build_info()'s source hash, and a summary with another stamp (or none) is not quoted.  -> (traffic bytes per launch
+    or None, file name or None, VALU-busy or None).  FETCH_SIZE is doubled as the MI355X guide prescribes for gfx950; both counters are in
+    KiB.  VALU-busy = SQ_ACTIVE_INST_VALU x 2 issue cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.txt")))
     for f in reversed(files):
         txt = open(f).read()
+        stamp = re.search(r"^# build src=([0-9a-f]+)", txt, re.M)
+        if not stamp or stamp.group(1) != build_src or kernel not in txt:
+            continue
         fe, wr = re.search(r"FETCH_SIZE\s+([0-9.e+]+)", txt), re.search(r"WRITE_SIZE\s+([0-9.e+]+)", txt)
-        if fe and wr and "smooth_spheres" in txt:
-            busy = None
-            av, ga = re.search(r"SQ_ACTIVE_INST_VALU\s+([0-9.e+]+)", txt), re.search(r"GRBM_GUI_ACTIVE\s+([0-9.e+]+)", txt)
-            if av and ga:   # one count per VALU instruction, 2 issue cycles each on gfx950; GRBM_GUI_ACTIVE sums 8 XCDs
-                busy = round(float(av.group(1)) * 2.0 / (1024.0 * float(ga.group(1)) / 8.0), 3)
-            return int((2.0 * float(fe.group(1)) + float(wr.group(1))) * 1024), os.path.basename(f), busy
+        av, ga = re.search(r"SQ_ACTIVE_INST_VALU\s+([0-9.e+]+)", txt), re.search(r"GRBM_GUI_ACTIVE\s+([0-9.e+]+)", txt)
+        busy = round(float(av.group(1)) * 2.0 / (1024.0 * float(ga.group(1)) / 8.0), 3) if av and ga else None
+        traffic = int((2.0 * float(fe.group(1)) + float(wr.group(1))) * 1024) if fe and wr else None
+        if busy is not None or traffic is not None:
+            return traffic, os.path.basename(f), busy
     return None, None, None
 
 
@@ -355,7 +359,10 @@ def main():
         mrays = rays / dt / 1e6
         # roofline of the dominant (only) kernel, from this rank's launches: algorithmic lane-ops per
         # launch / mean HIP-event duration of a launch
-        traffic, traffic_src, valu_busy = pmc_traffic_bytes() if (W == 4096 and world == 1) else (None, None, None)
+        build = ft.build_info()
+        traffic, traffic_src, valu_busy = profile_figures(build["src"], "ft_trace_kernel_smooth_spheres  ") if (W == 4096 and world == 1) else (None, None, None)
+        if traffic_src is None:
+            traffic_src = "no profiles/*_summary.txt carries the stamp of this build (src=%s): traffic / valu_busy_pmc not quoted" % build["src"]
         flops_launch = algorithmic_flops(st, args.spheres) / args.steps
         launch_s = st["kernel_ms"] / 1e3 / args.steps
         achieved = flops_launch / launch_s / 1e12
@@ -364,7 +371,7 @@ def main():
                       "(delta is measured against the CPU oracle: F# parity is unpinned, DESIGN.md section 2)",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build": build,
             "config": {"workload": f"C3: unionSmooth(0.25) of {args.spheres} spheres, {W}x{H}, 1 spp, 1 directional light "
                                    "(shadow rays = secondary rays), eps 0.01, ray length 30",
                        "rays_per_frame": rays // args.steps, "primary": rays_primary // args.steps,
@@ -409,16 +416,30 @@ def main():
             out["config"]["max_abs_delta_vs_oracle"] = check["max_abs_delta"]      # second half of the metric: 0.0 = bit-exact
             out["config"]["pixels_compared_with_oracle"] = check["pixels"]
             if console is not None:
-                out["config"]["program_fs_scene"] = program_fs_block(console, cam, args.steps)
+                out["config"]["program_fs_scene"] = program_fs_block(console, cam, args.steps, build["src"])
             if libm is not None:
                 out["config"]["glibc_math_mode"] = libm_block(libm, scene, cam, W, H)
+        elif world > 1:
+            # N > 1: the gathered frame gets its own parity flag — a few columns against the oracle, after the timed region
+            out["config"].update(oracle_check_columns(scene, cam, W, H, pipe.frame, 16))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def program_fs_block(console, cam, steps):
+def oracle_check_columns(scene, cam, W, H, frame, ncols):
+    """max |delta| of `ncols` evenly spaced columns of a device frame against the CPU oracle (the checker, never the thing measured)"""
+    import numpy as np
+    from oracle import binding as ob
+    xstep = max(1, W // ncols)
+    img, _ = ob.Oracle().scene(scene).render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=host_cpu_share())
+    got = frame[::xstep].cpu().numpy()
+    delta = float(np.max(np.abs(got.astype(np.float64) - img.astype(np.float64)))) if got.shape == img.shape else float("nan")
+    return {"max_abs_delta_vs_oracle": delta, "pixels_compared_with_oracle": int(img.shape[0] * img.shape[1])}
+
+
+def program_fs_block(console, cam, steps, build_src):
     """Side block for the reference's own workload (src/FrayTracer.Console/Program.fs:14-83: System.Random(19), 1000 tori,
     subtract(intersect(union, sphere), sphere), 2 lights) at 4000^2 on the general grid-union kernel: Mrays/s, and its own
     roofline entry priced as SURVEY.md section 8d prescribes for unions, with the oracle's counters of a column sample of the same
@@ -432,20 +453,32 @@ def program_fs_block(console, cam, steps):
     got = console["frame"][::xstep].cpu().numpy()
     delta = float(np.max(np.abs(got.astype(np.float64) - img.astype(np.float64))))
     flops_per_eval = union_algorithmic_flops(cnt) / max(1, cnt["root_evals"])
+    # what the kernel executes: it leaves a cell's sorted list at the first failing LowerBound test (exact), so it looks at `union_tested`
+    # candidates where the reference scans `union_candidates` (both from the oracle's counters of the sampled columns)
+    executed = dict(cnt); executed["union_candidates"] = cnt["union_tested"]
+    flops_per_eval_executed = union_algorithmic_flops(executed) / max(1, cnt["root_evals"])
     evals = cst["sdf_evals"] / steps
     kernel_s = cst["kernel_ms"] / 1e3 / steps
     rays = (cst["rays_primary"] + cst["rays_shadow"]) / steps
     achieved = flops_per_eval * evals / kernel_s / 1e12
+    achieved_executed = flops_per_eval_executed * evals / kernel_s / 1e12
+    _, prof_src, valu_busy = profile_figures(build_src, "# case: Program.fs scene 4000^2")
     return {"workload": f"Program.fs scene, {CW}x{CW}, 1 spp, directional + point light", "value": round(rays / kernel_s / 1e6, 1), "unit": "Mrays/s",
             "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals),
             "lane_utilisation": round(cst["sdf_evals"] / (64.0 * max(1, cst["wave_evals"])), 4), "shader_mhz": round(cst["shader_mhz"], 1),
             "max_abs_delta_vs_oracle": delta, "pixels_compared_with_oracle": int(img.shape[0] * img.shape[1]),
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "algorithmic_flops_per_eval": round(flops_per_eval, 1),
+            "roofline": {"bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
+                         "achieved_reference_work": round(achieved, 3), "frac_reference_work": round(achieved / VALU_PEAK_TLANEOPS, 4),
+                         "achieved_executed": round(achieved_executed, 3), "frac_executed": round(achieved_executed / VALU_PEAK_TLANEOPS, 4),
+                         "valu_busy_pmc": valu_busy, "valu_busy_source": prof_src,
+                         "algorithmic_flops_per_eval_reference": round(flops_per_eval, 1), "algorithmic_flops_per_eval_executed": round(flops_per_eval_executed, 1),
                          "candidates_per_eval_reference": round(cnt["union_candidates"] / max(1, cnt["root_evals"]), 2),
+                         "candidates_per_eval_executed": round(cnt["union_tested"] / max(1, cnt["root_evals"]), 2),
                          "primitive_evals_per_eval": round(sum(cnt["prim"]) / max(1, cnt["root_evals"]), 2),
-                         "note": "the reference scans a cell's whole candidate list (13 flops per candidate); the kernel leaves the sorted "
-                                 "list at the first failing LowerBound test (exact), so it executes fewer than the priced operations"}}
+                         "note": "frac_reference_work prices the reference's own work (it scans a cell's whole candidate list, 13 flops per candidate): an "
+                                 "algorithmic speed-up figure, not a hardware fraction.  frac_executed prices what the kernel executes: it leaves the sorted list "
+                                 "at the first failing LowerBound test (exact), i.e. candidates_per_eval_executed of them.  valu_busy_pmc: PMC of a committed "
+                                 "profile of this same build and size, or null"}}
 
 
 def libm_block(libm, scene, cam, W, H):

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libft_oracle.so")
 class Counters(C.Structure):
     _fields_ = [("prim", C.c_uint64 * 8)] + [(k, C.c_uint64) for k in (
         "root_evals", "march_steps", "rays_primary", "rays_shadow", "rays_ext", "hits_primary", "hits_shadow",
-        "smooth_children", "union_candidates", "flags")]
+        "smooth_children", "union_candidates", "flags", "union_tested")]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "prim"}

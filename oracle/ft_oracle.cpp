@@ -186,6 +186,8 @@ struct Counters {
     uint64_t smooth_children;  // exp() calls in unionSmooth
     uint64_t union_candidates; // candidates visited (both tests evaluated) in union loops
     uint64_t flags;
+    uint64_t union_tested;     // of those, the candidates up to and including the first one whose :30 test fails — all that a walk needs to
+                               // look at which knows that the list is sorted by LowerBound (measurement only: what the GPU walk executes)
 };
 thread_local Counters tl_cnt;
 
@@ -346,10 +348,12 @@ SdfForm Form_union(const std::vector<SdfForm>& forms, std::string& err) {    // 
         const LookupCell& cell = grid->lookup(position);                     // :23
         float distanceToCenter = Distance(cell.Center, position);            // :25
         float min = (*items)[cell.Items[0].Item].Distance(position);         // :26
+        bool sortedWalkDone = false;                                         // (counter only)
         for (size_t i = 1; i < cell.Items.size(); ++i) {                     // :27
             const LookupItem& sdf = cell.Items[i];
             const SdfForm& item = (*items)[sdf.Item];
             tl_cnt.union_candidates++;
+            if (!sortedWalkDone) { tl_cnt.union_tested++; if (!(min > sdf.LowerBound - distanceToCenter)) sortedWalkDone = true; }
             if (min > sdf.LowerBound - distanceToCenter                      // :30
                 && min > getMinDistance(item.Boundary, position)) {          // :31
                 min = fs_min(min, item.Distance(position));                  // :33
@@ -894,7 +898,7 @@ void addCounters(Counters& a, const Counters& b) {
     a.rays_primary += b.rays_primary; a.rays_shadow += b.rays_shadow; a.rays_ext += b.rays_ext;
     a.hits_primary += b.hits_primary; a.hits_shadow += b.hits_shadow;
     a.smooth_children += b.smooth_children; a.union_candidates += b.union_candidates;
-    a.flags |= b.flags;
+    a.flags |= b.flags; a.union_tested += b.union_tested;
 }
 
 }  // namespace
@@ -908,7 +912,7 @@ extern "C" {
 typedef struct orc_counters {
     uint64_t prim[8];
     uint64_t root_evals, march_steps, rays_primary, rays_shadow, rays_ext;
-    uint64_t hits_primary, hits_shadow, smooth_children, union_candidates, flags;
+    uint64_t hits_primary, hits_shadow, smooth_children, union_candidates, flags, union_tested;
 } orc_counters;
 
 const char* orc_last_error(void) { return g_err.c_str(); }

@@ -21,6 +21,8 @@ cases = [("C1 sphere 256^2", syn.config1()[0], 256), ("C2 union32 1024^2", syn.c
          ("C2 union32+boxes 1024^2", syn.config2(boxes=True)[0], 1024),
          ("console-like 1000 tori 1000^2", syn.console_like(n=1000)[0], 1000),
          ("console-like 1000 tori 4000^2", syn.console_like(n=1000)[0], 4000),
+         # the reference's own workload (Program.fs:14-83: System.Random(19), 1000 tori, subtract(intersect(union)), 2 lights) at its own size and at 4000^2
+         ("Program.fs scene 1000^2", syn.console_scene()[0], 1000), ("Program.fs scene 4000^2", syn.console_scene()[0], 4000),
          ("C2 union32 4096^2", syn.config2()[0], 4096),
          ("mixed nested 1024^2", syn.mixed_nested()[0], 1024),
          ("crowd of 300 combinator objects 2048^2", syn.combinator_crowd()[0], 2048),

@@ -7,4 +7,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/tools/bench_scenes.py" "$CASE" > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 "$REPO/tools/bench_scenes.py" "$CASE" > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- python3 "$REPO/tools/bench_scenes.py" "$CASE" > "$OUT/pmc_sq2.log" 2>&1
-cd "$REPO"; python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"
+cd "$REPO"; { echo "# case: $CASE (tools/bench_scenes.py; every launch of the profiled process is this one scene at this one size)"; python3 tools/summarize_prof.py "$OUT"; } > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"

@@ -7,6 +7,16 @@ from collections import defaultdict
 
 out = sys.argv[1]
 
+# stamp: which sources the profiled library was built from (bench.py quotes PMC figures only from a summary whose stamp equals the
+# hash of the library it runs on; fraytracer_amd/csrc/source_hash.py --rev <commit> maps a hash to a commit)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import fraytracer_amd as _ft
+    _info = _ft.build_info()
+    print(f"# build src={_info['src']} kind={_info['kind']}")
+except Exception as e:                                             # noqa: BLE001 - the summary is still useful without the stamp
+    print(f"# build unknown ({e})")
+
 
 def rows(pattern):
     for f in glob.glob(os.path.join(out, pattern), recursive=True):
