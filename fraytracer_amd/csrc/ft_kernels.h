@@ -7,13 +7,17 @@
 #include "ft_device.h"
 
 #define FT_BLOCK 256          // 4 waves; every wave is an independent persistent worker
-// dynamic LDS of a trace workgroup starts with FT_LDS_STAT_ROWS rows of per-lane statistics words and 4 clock dwords
+// dynamic LDS of a trace workgroup starts with a header: 64 words (per-wave statistics, the reporting wave's start clocks), in the diagnostic
+// build 13 rows of per-lane union-walk counters (kernels.hip FT_UDBG: 12 + 1 scratch row), then FT_SH_ROWS rows of per-lane shading state
+#define FT_LDS_CNT_WORDS 64
 #ifdef FT_UNION_PROFILE
-#define FT_LDS_STAT_ROWS 20   // diagnostic build: + 12 rows of union-walk counters (kernels.hip FT_UDBG) + 1 scratch row
+#define FT_LDS_DBG_ROWS 13
 #else
-#define FT_LDS_STAT_ROWS 7
+#define FT_LDS_DBG_ROWS 0
 #endif
-#define FT_LDS_HDR_FLOATS (FT_LDS_STAT_ROWS * FT_BLOCK + 4)
+#define FT_SH_ROWS 13         // hit position, normal, accumulated light, current light's intensity (3 each), its cosine
+#define FT_LDS_SH_BASE (FT_LDS_CNT_WORDS + FT_LDS_DBG_ROWS * FT_BLOCK)
+#define FT_LDS_HDR_FLOATS (FT_LDS_SH_BASE + FT_SH_ROWS * FT_BLOCK)
 
 struct FtRenderArgs {
     FtSceneDev S;

@@ -70,15 +70,30 @@ __device__ __forceinline__ FtLight ld_light(const FtLight FT_CONST* q) {
 // does not depend on the scene: primitives can raise a flag without being handed a pointer.
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float ft_lds[];
-enum : uint32_t { FT_C_EVALS = 0, FT_C_SHADOW, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
-static_assert(FT_C_COUNT <= FT_LDS_STAT_ROWS, "ft_kernels.h: FT_LDS_STAT_ROWS");
-// behind the statistics rows: 4 dwords holding the start clocks of the workgroup's first wave (FT_LDS_HDR_FLOATS in total)
+enum : uint32_t { FT_C_SHADOW = 0, FT_C_HITP, FT_C_HITS, FT_C_PRIMARY, FT_C_FLAGS, FT_C_EXT, FT_C_COUNT };
+static_assert(FT_C_COUNT * (FT_BLOCK / 64) <= 32, "ft_kernels.h: the statistics words of the LDS header");
+// Statistics are per WAVE: word k * 4 + wave of the header (round 2 kept one word per lane and counter: 7 KB per workgroup, which now
+// holds the lanes' shading state instead).  The lanes that reach a counting site together add their number with ONE ds_add by their first
+// lane; scene evaluations are not counted here at all (a wave-uniform register in ft_trace_body).  Behind the 32 words: the start clocks
+// of the workgroup's first wave.  The header's address does not depend on the scene: a primitive can raise a flag without a pointer.
 __device__ __forceinline__ void ft_count(uint32_t k) {
-    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + k * FT_BLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long m = __ballot(1);                          // the lanes executing this call
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1))
+        __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + k * (FT_BLOCK / 64) + (threadIdx.x >> 6), (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void ft_flag(uint32_t bits) {
-    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + FT_C_FLAGS * FT_BLOCK, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ void ft_flag(uint32_t bits) {              // `bits` is a constant of the call site
+    const unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1))
+        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(ft_lds) + FT_C_FLAGS * (FT_BLOCK / 64) + (threadIdx.x >> 6), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// A lane's shading state — hit position, normal (and the three probes before it), accumulated light, the current light's contribution —
+// is touched only between marches, so it lives in per-lane LDS rows (row r of thread t at FT_LDS_SH_BASE + r * FT_BLOCK + t: conflict-free),
+// not in 13 registers that would stay live across every scene evaluation: that is what lets the general kernels keep more waves resident.
+enum : uint32_t { FT_SH_HP = 0, FT_SH_NRM = 3, FT_SH_LACC = 6, FT_SH_LINT = 9, FT_SH_LCOS = 12 };
+static_assert(FT_SH_LCOS < FT_SH_ROWS, "ft_kernels.h: FT_SH_ROWS");
+__device__ __forceinline__ float* ft_sh(uint32_t row) { return ft_lds + FT_LDS_SH_BASE + row * FT_BLOCK + threadIdx.x; }
+__device__ __forceinline__ f3 sh_get3(uint32_t row) { const float* q = ft_sh(row); return mk3(q[0], q[FT_BLOCK], q[2 * FT_BLOCK]); }
+__device__ __forceinline__ void sh_set3(uint32_t row, f3 v) { float* q = ft_sh(row); q[0] = v.x; q[FT_BLOCK] = v.y; q[2 * FT_BLOCK] = v.z; }
 
 // ---- arithmetic of MathF.Exp / MathF.Log (FT_OPT_MATH) ------------------------------------------------------------------------
 // MATH = 0: the fixed algorithms of ft_math.h (same bits on every machine; the default).  MATH = 1: glibc's expf / logf restated
@@ -385,7 +400,7 @@ __device__ __forceinline__ bool fast_point_ok(f3 p) {
 __device__ unsigned long long ft_union_dbg[12];   // [8] shader cycles a wave waits for the candidate records of a trip, [9] cycles in candidate evaluations,
                                                   // [10] wave-level evaluations x 64 whose active lanes share ONE lookup cell, [11] ... the same cell as the evaluation before
 __device__ __forceinline__ void ft_dbg_add(uint32_t k, uint32_t v) {
-    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + threadIdx.x + (7u + k) * FT_BLOCK, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(ft_lds) + FT_LDS_CNT_WORDS + threadIdx.x + k * FT_BLOCK, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ bool ft_dbg_leader() { return (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1); }
 __device__ __forceinline__ uint32_t ft_dbg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return (uint32_t)t; }
@@ -421,7 +436,7 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     {
         const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
         const bool uni = __ballot(cell != u) == 0ull;
-        uint32_t* prev = reinterpret_cast<uint32_t*>(ft_lds) + 19u * FT_BLOCK + (threadIdx.x & ~63u);
+        uint32_t* prev = reinterpret_cast<uint32_t*>(ft_lds) + FT_LDS_CNT_WORDS + 12u * FT_BLOCK + (threadIdx.x & ~63u);
         if (uni) { FT_UDBG_WAVE(10); if (*prev == u) FT_UDBG_WAVE(11); }
         if (ft_dbg_leader()) *prev = uni ? u : 0xffffffffu;
     }
@@ -895,11 +910,8 @@ struct LaneState {
     uint32_t phase, job, steps, lidx, leaf, outIdx;
     f3 o, dir;            // current ray (primary, then the shadow ray of light lidx)
     float len, eps;
-    f3 hp;                // result.Ray.Origin after Ray.move -eps (SdfObject.fs:73) = result.Position
-    f3 nrm;               // NX..NZ: the three probes; afterwards the normal
-    f3 lacc;              // lightColor (SdfScene.fs:12)
-    f3 lint;              // intensity the current light adds when unshadowed
-    float lcos;
+    // in LDS (ft_sh rows), not here: hp = result.Ray.Origin after Ray.move -eps (SdfObject.fs:73) = result.Position; nrm = the three probes
+    // NX..NZ, afterwards the normal; lacc = lightColor (SdfScene.fs:12); lint = intensity the current light adds when unshadowed; lcos
     uint32_t aoIdx, aoOpen;   // EXTENSION: ambient-occlusion ray counter / unoccluded count
     float sign;               // EXTENSION glass: +1 outside, -1 inside (the march runs on sign * Distance)
     f3 thr;                   // EXTENSION: path throughput (wavelength weight x tints)
@@ -956,20 +968,20 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
         if (EXT && s.phase == PH_AONEXT) {                             // EXTENSION
             if (s.aoIdx >= a.aoSamples) {
                 const float f = (float)s.aoOpen / (float)a.aoSamples;
-                s.lacc = mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]) * f;
+                sh_set3(FT_SH_LACC, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]) * f);
                 s.lidx = 0; s.phase = PH_LIGHTS;
                 continue;
             }
-            const f3 dir = ft_normalize(s.nrm + mk3(FT_AO_DIRS[s.aoIdx][0], FT_AO_DIRS[s.aoIdx][1], FT_AO_DIRS[s.aoIdx][2]));
+            const f3 dir = ft_normalize(sh_get3(FT_SH_NRM) + mk3(FT_AO_DIRS[s.aoIdx][0], FT_AO_DIRS[s.aoIdx][1], FT_AO_DIRS[s.aoIdx][2]));
             ft_count(FT_C_EXT);
             if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.aoOpen += 1; s.aoIdx += 1; continue; }
-            s.o = s.hp; s.dir = dir; s.len = a.aoRadius; s.steps = 0;
+            s.o = sh_get3(FT_SH_HP); s.dir = dir; s.len = a.aoRadius; s.steps = 0;
             s.phase = PH_AO;
             continue;
         }
         if (s.phase == PH_SHADOW) {
             if (s.len <= 0.0f) {                                       // shadow ray missed: light arrives
-                s.lacc = s.lacc + s.lint * s.lcos;                     // SdfScene.fs:23
+                sh_set3(FT_SH_LACC, sh_get3(FT_SH_LACC) + sh_get3(FT_SH_LINT) * *ft_sh(FT_SH_LCOS));   // SdfScene.fs:23
                 s.lidx += 1; s.phase = PH_LIGHTS;
                 continue;
             }
@@ -979,7 +991,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             if (s.lidx >= a.S.nLights) {                               // SdfScene.fs:28
                 cfp m = as_const(a.S.materials) + 3u * s.leaf;
                 const f3 color = mk3(m[0], m[1], m[2]);
-                emit<EXT>(a, s, color * (s.lacc * piInv));
+                emit<EXT>(a, s, color * (sh_get3(FT_SH_LACC) * piInv));
                 s.phase = PH_IDLE;
                 return;
             }
@@ -987,20 +999,21 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             const f3 lv = mk3(L.v[0], L.v[1], L.v[2]);
             const f3 lc = mk3(L.color[0], L.color[1], L.color[2]);
             f3 ldir;
+            const f3 hp = sh_get3(FT_SH_HP);
             if (L.type == FT_LIGHT_DIRECTIONAL) ldir = lv;             // SdfLight.fs:9
-            else ldir = ft_normalize(lv - s.hp);                       // SdfLight.fs:25
-            const float lightCos = ft_dot(s.nrm, ldir);                // SdfScene.fs:15
+            else ldir = ft_normalize(lv - hp);                         // SdfLight.fs:25
+            const float lightCos = ft_dot(sh_get3(FT_SH_NRM), ldir);   // SdfScene.fs:15
             if (lightCos > 0.0f) {                                     // SdfScene.fs:17
-                s.lcos = lightCos;
-                s.o = s.hp;
+                *ft_sh(FT_SH_LCOS) = lightCos;
+                s.o = hp;
                 if (L.type == FT_LIGHT_DIRECTIONAL) {                  // SdfLight.fs:11-16
-                    s.dir = lv; s.len = 1000.0f; s.lint = lc;
+                    s.dir = lv; s.len = 1000.0f; sh_set3(FT_SH_LINT, lc);
                 } else {                                               // SdfLight.fs:27-37
-                    const f3 diff = lv - s.hp;
+                    const f3 diff = lv - hp;
                     const float distance2 = ft_length2(diff);
                     s.dir = diff / distance2;                          // not unit: reference quirk
                     s.len = sqrtf(distance2);
-                    s.lint = lc / distance2;                           // :40
+                    sh_set3(FT_SH_LINT, lc / distance2);               // :40
                 }
                 s.steps = 0; ft_count(FT_C_SHADOW);
                 s.phase = PH_SHADOW;
@@ -1061,7 +1074,7 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
         if (s.sign < 0.0f) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; }     // diffuse seen from inside: absorbed
         return;
     }
-    const f3 N = s.nrm, D = s.dir;
+    const f3 N = sh_get3(FT_SH_NRM), D = s.dir, hp = sh_get3(FT_SH_HP);
     if (s.bounce >= a.maxBounces || N.x != N.x || N.y != N.y || N.z != N.z) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; return; }
     float cosi = -ft_dot(N, D);
     if (!(cosi > 0.0f)) cosi = 0.0f;
@@ -1087,10 +1100,10 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
     ft_count(FT_C_EXT);
     if (reflect) {
         s.dir = ft_normalize(D + N * (2.0f * cosi));                   // Light.fs:56
-        s.o = s.hp + N * (2.0f * s.eps);
+        s.o = hp + N * (2.0f * s.eps);
     } else {
         s.dir = ft_normalize(D * eta + N * (eta * cosi - cost));       // Light.fs:58
-        s.o = s.hp - N * (4.0f * s.eps);
+        s.o = hp - N * (4.0f * s.eps);
         s.sign = -s.sign;
         if (s.sign < 0.0f) { cfp t = as_const(a.S.materials) + 3u * s.leaf; s.thr = s.thr * mk3(t[0], t[1], t[2]); }
     }
@@ -1109,25 +1122,29 @@ template <int VARIANT, bool EXT, int MATH = 0>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the first wave of block 0 reports the shader clock it ran at (statistics only); its start clocks wait in LDS, not in registers
-    unsigned long long* clk0 = reinterpret_cast<unsigned long long*>(ft_lds + FT_LDS_STAT_ROWS * FT_BLOCK);
+    unsigned long long* clk0 = reinterpret_cast<unsigned long long*>(ft_lds + 32);
     if (blockIdx.x == 0 && tid == 0) { clk0[0] = clock64(); clk0[1] = wall_clock64(); }
     float* sd = ft_lds + FT_LDS_HDR_FLOATS + tid;
     uint32_t* sl = reinterpret_cast<uint32_t*>(ft_lds + FT_LDS_HDR_FLOATS + a.S.nSlots * FT_BLOCK) + tid;
     float* ldsC = ft_lds + FT_LDS_HDR_FLOATS + 2u * a.S.nSlots * FT_BLOCK; // staged constant pool ("SDF op stack" in LDS)
     for (uint32_t i = tid; i < a.S.nStage; i += FT_BLOCK) ldsC[i] = a.S.consts[i];
     if (MATH != 0 && tid < FT_LIBM_TAB_DOUBLES) const_cast<ft_u64*>(ft_libm_tab(a.S))[tid] = ft_libm_tab_g[tid];   // FT_OPT_MATH: glibc's tables
-    for (uint32_t k = 0; k < FT_LDS_STAT_ROWS; ++k) reinterpret_cast<uint32_t*>(ft_lds)[tid + k * FT_BLOCK] = 0u;
+    if (tid < 32u) reinterpret_cast<uint32_t*>(ft_lds)[tid] = 0u;       // the per-wave statistics words
+#ifdef FT_UNION_PROFILE
+    for (uint32_t k = 0; k < FT_LDS_DBG_ROWS; ++k) reinterpret_cast<uint32_t*>(ft_lds)[FT_LDS_CNT_WORDS + tid + k * FT_BLOCK] = 0u;
+#endif
     __syncthreads();
 
     float* coopRow = ft_lds + ft_coop_lds_offset(a.S, MATH != 0) + (tid >> 6) * FT_COOP_SEG;   // lean kernel: this wave's row of the latency mode
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
     uint32_t waveEvals = 0;                                            // evaluation rounds of this wave (lane-utilisation statistic)
     uint32_t coopEvals = 0;                                            // evaluations done in latency mode (wave-uniform)
+    uint32_t nEvals = 0;                                               // scene evaluations of this wave's rays (wave-uniform: summed per round)
     bool exhausted = false;
     LaneState s;
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
-    s.o = s.dir = s.hp = s.nrm = s.lacc = s.lint = mk3(0, 0, 0);
-    s.len = 0; s.eps = 0; s.lcos = 0;
+    s.o = s.dir = mk3(0, 0, 0);
+    s.len = 0; s.eps = 0;
     s.aoIdx = s.aoOpen = 0;
     s.sign = 1.0f; s.thr = splat3(1.0f); s.bounce = 0; s.seed = 0;
 
@@ -1177,6 +1194,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         };
         // ---- latency mode: at most tailK rays left in this wave -> each is evaluated by all 64 lanes together ("Latency (tail) mode") ----
         const unsigned long long am = __ballot(active);
+        nEvals += (uint32_t)__popcll(am);
         const bool coop = (uint32_t)__popcll(am) <= a.tailK;           // tailK = 0: never
         float dCoop = 0.0f; uint32_t leafCoop = 0;
         if (coop && am != 0ull) {
@@ -1207,7 +1225,6 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
             }
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
-            ft_count(FT_C_EVALS);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
 
             switch (s.phase) {
@@ -1237,22 +1254,24 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 if (miss) s.len = -1.0f;                               // resolved as a miss by settle()
                 break;
             }
-            case PH_NX: s.nrm.x = d; s.phase = PH_NY; break;
-            case PH_NY: s.nrm.y = d; s.phase = PH_NZ; break;
-            case PH_NZ: s.nrm.z = d; s.phase = PH_NC; break;
+            case PH_NX: *ft_sh(FT_SH_NRM) = d; s.phase = PH_NY; break;
+            case PH_NY: *ft_sh(FT_SH_NRM + 1) = d; s.phase = PH_NZ; break;
+            case PH_NZ: *ft_sh(FT_SH_NRM + 2) = d; s.phase = PH_NC; break;
             case PH_NC: {
-                s.nrm = ft_normalize(s.nrm - splat3(d));               // SdfForm.fs:107-112
-                s.hp = s.o + s.dir * (-s.eps);                         // SdfObject.fs:73
-                s.lacc = mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]);         // SdfScene.fs:12
+                const f3 nrm = ft_normalize(sh_get3(FT_SH_NRM) - splat3(d));   // SdfForm.fs:107-112
+                const f3 hp = s.o + s.dir * (-s.eps);                  // SdfObject.fs:73
+                sh_set3(FT_SH_NRM, nrm);
+                sh_set3(FT_SH_HP, hp);
+                sh_set3(FT_SH_LACC, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));     // SdfScene.fs:12
                 s.lidx = 0;
                 s.phase = PH_LIGHTS;
                 if (EXT && a.aoSamples != 0u) { s.aoIdx = 0; s.aoOpen = 0; s.phase = PH_AONEXT; }   // EXTENSION
                 if (EXT && a.maxBounces != 0u) glass_bounce(a, s);     // EXTENSION
                 if (EXT && a.mode == 3u) {                             // SdfObject.tryTrace result (SdfObject.fs:72-77)
                     float* o = a.out + 16ull * s.outIdx;
-                    write_ray(o, s.hp, s.dir, s.len - (-s.eps), s.eps);            // Ray.move -eps: Length - (-eps)
+                    write_ray(o, hp, s.dir, s.len - (-s.eps), s.eps);              // Ray.move -eps: Length - (-eps)
                     cfp m = as_const(a.S.materials) + 3u * s.leaf;
-                    o[8] = s.nrm.x; o[9] = s.nrm.y; o[10] = s.nrm.z; o[11] = m[0]; o[12] = m[1]; o[13] = m[2];
+                    o[8] = nrm.x; o[9] = nrm.y; o[10] = nrm.z; o[11] = m[0]; o[12] = m[1]; o[13] = m[2];
                     reinterpret_cast<int32_t*>(o)[14] = 1; o[15] = 0.0f;
                     s.phase = PH_IDLE;
                 }
@@ -1266,13 +1285,9 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     }
 
     // ---- statistics -------------------------------------------------------------------------
-    const uint32_t* cw = reinterpret_cast<const uint32_t*>(ft_lds) + tid;
-    const unsigned long long e = wave_sum(cw[FT_C_EVALS * FT_BLOCK]), sh = wave_sum(cw[FT_C_SHADOW * FT_BLOCK]),
-                             hp = wave_sum(cw[FT_C_HITP * FT_BLOCK]), hs = wave_sum(cw[FT_C_HITS * FT_BLOCK]),
-                             pr = wave_sum(cw[FT_C_PRIMARY * FT_BLOCK]), ex = wave_sum(cw[FT_C_EXT * FT_BLOCK]);
-    const uint32_t cFlags = cw[FT_C_FLAGS * FT_BLOCK];
-    const unsigned long long fl = (__ballot((cFlags & 1u) != 0) ? 1ull : 0ull) | (__ballot((cFlags & 2u) != 0) ? 2ull : 0ull);
-    const unsigned long long fc = __ballot((cFlags & 4u) != 0) ? 4ull : 0ull;
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(ft_lds) + (tid >> 6);      // this wave's statistics words
+    const unsigned long long e = nEvals, sh = cw[FT_C_SHADOW * 4], hp = cw[FT_C_HITP * 4], hs = cw[FT_C_HITS * 4], pr = cw[FT_C_PRIMARY * 4], ex = cw[FT_C_EXT * 4];
+    const unsigned long long fl = cw[FT_C_FLAGS * 4] & 3u, fc = cw[FT_C_FLAGS * 4] & 4u;
     if (lane == 0) {
         atomicAdd(&a.stats->sdf_evals, e);
         atomicAdd(&a.stats->rays_shadow, sh);
@@ -1287,7 +1302,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     }
 #ifdef FT_UNION_PROFILE
     for (uint32_t k = 0; k < 12; ++k) {
-        const unsigned long long v = wave_sum(cw[(7u + k) * FT_BLOCK]);
+        const unsigned long long v = wave_sum(reinterpret_cast<const uint32_t*>(ft_lds)[FT_LDS_CNT_WORDS + tid + k * FT_BLOCK]);
         if (lane == 0 && v) atomicAdd(&ft_union_dbg[k], v);
     }
 #endif
