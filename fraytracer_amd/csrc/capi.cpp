@@ -58,6 +58,7 @@ struct ft_ctx {
     int optHostPin = 1;                                    // page-lock an unregistered ft_render destination for the call
     int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
     int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
+    int optGuided = 1;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel)
 };
 
 struct ft_scene {
@@ -259,6 +260,14 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     // step (march, the four normal probes, shadow rays), so a wave's lanes share lookup cells, list positions and branches.
     a.refillMin = (uint32_t)c->optRefillMin;               // 64 unless FT_OPT_REFILL_MIN says otherwise (experiments)
     a.tailK = (uint32_t)(c->optTailK >= 0 ? c->optTailK : (s->dev.fastPath == 1u ? FT_TAIL_K_LEAN : FT_TAIL_K_GENERAL));
+    // guided hand-out of the last jobs (kernels.hip refill): one half tile, then one quarter tile per resident wave — only where the latency
+    // mode makes a part-filled wave cheap (lean kernel, tailK >= 32) and only for the reference's sampling (tile-major job order)
+    a.shrink1 = a.shrink2 = a.nJobs;
+    if (s->dev.fastPath == 1u && a.tailK >= 32u && c->optGuided && a.mode == 0u) {
+        const uint64_t waves = (uint64_t)blocks * (FT_BLOCK / 64);
+        const uint64_t q = waves * (a.chunk / 4u), h = waves * (a.chunk / 2u);
+        if ((uint64_t)a.nJobs > 4u * (q + h)) { a.shrink2 = (uint32_t)(a.nJobs - q); a.shrink1 = (uint32_t)(a.nJobs - q - h); }
+    }
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
@@ -312,6 +321,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_HOST_CHUNKS: if (value < 0 || value > 16) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_CHUNKS: 0 (automatic) .. 16"); c->optHostChunks = value; return FT_OK;
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
     case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
+    case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_MATH:
         if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
         c->optMath = value; return FT_OK;
@@ -327,6 +337,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_HOST_PIN: *value = c->optHostPin; return FT_OK;
     case FT_OPT_MATH: *value = c->optMath; return FT_OK;
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
+    case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
 }

@@ -1160,12 +1160,23 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             if ((uint32_t)__popcll(idle) < a.refillMin && __ballot(s.phase >= PH_MARCH) != 0ull) break;
             if (chunkNext == chunkEnd) {
                 if (exhausted) break;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.counter, a.chunk);
+                // Guided hand-out at the end of the queue (lean kernel; everywhere else shrink1 = shrink2 = nJobs): from job shrink1 on a wave
+                // takes half a tile, from shrink2 on a quarter — the latency mode evaluates 32 / 16 rays with 2 / 4 lanes each at 60 % / 33 %
+                // of a full round's cost, so the last generation of work is spread over 2 - 4 times as many waves and drains that much
+                // sooner.  The cursor is read first to pick the size (one more global access per tile: ~0.1 % of a tile's time).
+                uint32_t base = 0, take = a.chunk;
+                if (lane == 0) {
+                    if (a.shrink1 < a.nJobs) {
+                        const uint32_t cur = __hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        take = cur >= a.shrink2 ? a.chunk / 4u : (cur >= a.shrink1 ? a.chunk / 2u : a.chunk);
+                    }
+                    base = atomicAdd(a.counter, take);
+                }
                 base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t took = (uint32_t)__builtin_amdgcn_readfirstlane((int)take);
                 if (base >= a.nJobs) { exhausted = true; break; }
                 chunkNext = base;
-                chunkEnd = (a.nJobs - base < a.chunk) ? a.nJobs : base + a.chunk;
+                chunkEnd = (a.nJobs - base < took) ? a.nJobs : base + took;
             }
             const uint32_t avail = chunkEnd - chunkNext;
             const uint32_t nIdle = (uint32_t)__popcll(idle);

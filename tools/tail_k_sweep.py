@@ -25,7 +25,7 @@ for name, scene, n, kw in cases:
     buf = torch.empty((cols, n, 3), dtype=torch.float32, device="cuda")
     row = {"scene": name}
     for k in ks:
-        dev.set_option("tail_k", k)
+        dev.set_option("tail_k", abs(k)); dev.set_option("guided", 0 if k < 0 else 1)          # a negative k: that threshold without the guided hand-out
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr(), **kw); ds.collect_stats()
         reps = 4
         for _ in range(reps):
