@@ -58,7 +58,8 @@ struct ft_ctx {
     int optHostPin = 1;                                    // page-lock an unregistered ft_render destination for the call
     int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
     int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
-    int optGuided = 1;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel)
+    int optChunk = 64;                                     // FT_OPT_CHUNK: jobs per grab (experiments: 64 = one 8x8 tile, 32, 16)
+    int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
 
 struct ft_scene {
@@ -252,7 +253,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
     // one 8x8 tile per grab: measured faster than larger chunks (lanes of a wave stay on neighbouring
     // pixels) and 2.6e5 atomics per 4096^2 frame are far below the rate one counter sustains
-    a.chunk = 64;
+    a.chunk = (uint32_t)c->optChunk;
     // burst refill (kernels.hip): a wave takes new rays only when all 64 lanes are idle, i.e. it works through one 8x8 tile at a
     // time.  Measured (profiles/r02_refill_sweep.txt, kernel ms at refillMin = 1 / 32 / 64): 1000-torus scene 4000^2 22.5 /
     // 15.8 / 12.1, at 1000^2 2.98 / 2.72 / 2.24, C2 4096^2 4.90 / 4.40 / 3.84, 300 on-demand combinators 24.6 / 14.8 / 10.3,
@@ -321,6 +322,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_HOST_CHUNKS: if (value < 0 || value > 16) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_CHUNKS: 0 (automatic) .. 16"); c->optHostChunks = value; return FT_OK;
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
     case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
+    case FT_OPT_CHUNK: if (value != 64 && value != 32 && value != 16) return setErr(FT_ERR_INVALID, "FT_OPT_CHUNK: 64, 32 or 16"); c->optChunk = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_MATH:
         if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
@@ -338,6 +340,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_MATH: *value = c->optMath; return FT_OK;
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
+    case FT_OPT_CHUNK: *value = c->optChunk; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
 }

@@ -116,7 +116,8 @@ typedef enum ft_option {
     FT_OPT_TAIL_K = 5,            /* latency mode: a wave holding at most this many rays evaluates them one at a time with all 64 lanes;
                                    * -1 (default) = the kernel's own threshold, 0 = off, 1..64 */
     FT_OPT_MATH = 6,              /* ft_math_mode (below); default FT_MATH_FIXED */
-    FT_OPT_GUIDED = 7             /* 1 (default): the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0: whole tiles only */
+    FT_OPT_CHUNK = 8,             /* 64 (default): rays a wave takes per grab = one 8x8 tile; 32 / 16: half / quarter tiles (experiments) */
+    FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's
  * expf / logf / powf under .NET: platform arithmetic, not one fixed function.

@@ -266,6 +266,29 @@ def test_latency_mode_is_bit_identical(gpu, oracle, k):
         gpu.set_option("tail_k", -1)
 
 
+def test_hand_out_options_do_not_change_the_frame(gpu, oracle):
+    """FT_OPT_CHUNK (rays per grab: whole, half, quarter tiles) and FT_OPT_GUIDED (shrinking grabs at the end of the queue) only change which
+    wave renders which pixel: the frame and the counters stay those of the oracle"""
+    cam = syn.default_camera()
+    scene, _ = syn.config3(n=64, size=200)
+    ds, os_ = both(gpu, oracle, scene)
+    want, ocnt = os_.render(EPS, LEN, 200, 136, cam.as_array())
+    try:
+        for chunk, guided, k in ((64, 1, 32), (32, 0, 32), (16, 0, 32), (32, 1, 0), (16, 0, 2), (64, 0, -1)):
+            gpu.set_option("chunk", chunk); gpu.set_option("guided", guided); gpu.set_option("tail_k", k)
+            g, gst = ds.render(EPS, LEN, ft.ImageSize(200, 136), cam)
+            assert_bit_equal(g, want, f"chunk {chunk}, guided {guided}, tail_k {k}")
+            check_counts(gst, ocnt)
+        c2, _ = syn.config2(seed=9, size=96)
+        ds2, os2 = both(gpu, oracle, c2)
+        want2, _ = os2.render(EPS, LEN, 96, 96, cam.as_array())
+        for chunk in (32, 16):
+            gpu.set_option("chunk", chunk)
+            assert_bit_equal(ds2.render(EPS, LEN, ft.ImageSize(96, 96), cam)[0], want2, f"C2, chunk {chunk}")
+    finally:
+        gpu.set_option("chunk", 64); gpu.set_option("guided", 0); gpu.set_option("tail_k", -1)
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
