@@ -17,6 +17,11 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 big = len(sys.argv) > 3 and sys.argv[3] == "big"          # unions of 60-400 objects, larger images
 dev = ft.Device(0)
+from _opts import apply_env_options
+applied = apply_env_options(dev)                    # FT_TAIL_K=64: every evaluation through the latency mode; FT_MATH=1|2: glibc arithmetic ...
+if "math" in applied and applied["math"] != 0:
+    ob.lib.orc_set_libm(1)                          # ... against the oracle calling this machine's expf / logf (FT_MATH must name the build libm resolves to)
+    assert applied["math"] == ft.glibc_build_of_this_host(), "FT_MATH must be the glibc build of this host"
 bad, skipped, flagged, rays, glassy = [], 0, 0, 0, 0
 t0 = time.time()
 for seed in range(first, first + count):
@@ -42,7 +47,7 @@ for seed in range(first, first + count):
     ds.close()
     if (seed - first) % 50 == 49:
         print(f"... {seed - first + 1} scenes, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(json.dumps({"big": big, "first_seed": first, "scenes": count, "rejected_by_both": skipped, "with_nan_or_cap_flags": int(flagged),
+print(json.dumps({"options": applied, "build": ft.build_info()["src"], "big": big, "first_seed": first, "scenes": count, "rejected_by_both": skipped, "with_nan_or_cap_flags": int(flagged),
                   "with_extension_rays": int(glassy), "rays": int(rays), "mismatching_scenes": len(bad), "mismatches": bad[:20],
                   "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if bad else 0)
