@@ -458,7 +458,12 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     while (i < end) {
         const uint32_t j = i + 1u < end ? i + 1u : i;
         FT_UDBG_T0(tLoad);
-        const ItemRegs ra = ld_item_at(items, i), rb = ld_item_at(items, j);
+        ItemRegs ra = ld_item_at(items, i), rb = ld_item_at(items, j);
+        // Both records are requested before anything waits for either: left alone, the compiler sinks B's loads behind A's tests (two memory
+        // round trips per trip).  Neutral where waves share a SIMD six-fold (Program.fs scene at 4000^2: 12.00 -> 12.03 ms), -5 % where the frame
+        // is small and the walk runs at its own latency (the reference's 1000^2: 2.28 -> 2.17 ms); a max-norm pre-test that skips both roots
+        // where no lane can pass :31 was measured at the same time and is slower (+3 %: profiles/r03_walk_variants.txt).
+        asm volatile("" : "+v"(ra.a), "+v"(ra.b), "+v"(rb.a), "+v"(rb.b));
 #ifdef FT_UNION_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
