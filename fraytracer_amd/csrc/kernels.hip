@@ -462,7 +462,9 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
         // Both records are requested before anything waits for either: left alone, the compiler sinks B's loads behind A's tests (two memory
         // round trips per trip).  Neutral where waves share a SIMD six-fold (Program.fs scene at 4000^2: 12.00 -> 12.03 ms), -5 % where the frame
         // is small and the walk runs at its own latency (the reference's 1000^2: 2.28 -> 2.17 ms); a max-norm pre-test that skips both roots
-        // where no lane can pass :31 was measured at the same time and is slower (+3 %: profiles/r03_walk_variants.txt).
+        // where no lane can pass :31 was measured at the same time and is slower (+3 %: profiles/r03_walk_variants.txt).  So is a walk that always
+        // consumes both candidates of a trip (B's right-hand sides kept across A's evaluation, two evaluation sites): bit-exact, 4 spills at 80
+        // registers, +1 % at 4000^2 and +4 % at 1000^2 (same file).
         asm volatile("" : "+v"(ra.a), "+v"(ra.b), "+v"(rb.a), "+v"(rb.b));
 #ifdef FT_UNION_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -46,10 +46,12 @@ for name, scene, n, *rest in cases:
     st = ds.collect_stats()
     rays = (st["rays_primary"] + st["rays_shadow"] + st["rays_ext"]) / reps
     ms = st["kernel_ms"] / reps
-    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, **kw)      # first call allocates staging buffers
-    t0 = time.perf_counter()
-    img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, **kw)      # host output: includes the device->host copy
-    t_host = time.perf_counter() - t0
+    t_host = float("nan")
+    if not os.environ.get("FT_KERNEL_ONLY"):                                # (profile_scene.sh: only whole-frame launches in the trace)
+        img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, **kw)      # first call allocates staging buffers
+        t0 = time.perf_counter()
+        img, st2 = ds.render(syn.EPSILON, syn.RAY_LENGTH, size, cam, **kw)      # host output: includes the device->host copy
+        t_host = time.perf_counter() - t0
     print(json.dumps({"scene": name, "kernel_ms": round(ms, 3), "Mrays/s": round(rays / ms / 1e3, 2),
                       "rays": int(rays), "evals_per_ray": round(st["sdf_evals"] / reps / rays, 2),
                       "lane_util": round(st["sdf_evals"] / (64.0 * st["wave_evals"]), 4),
