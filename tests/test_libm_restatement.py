@@ -24,6 +24,8 @@ Y_GAMMA = float(np.float32(1.0) / np.float32(2.2))                   # Image.fs:
 
 
 def checker():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     lib = C.CDLL(LIB)
     lib.chk_compare.restype = C.c_uint64
     lib.chk_compare.argtypes = [C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
