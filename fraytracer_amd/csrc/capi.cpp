@@ -202,8 +202,11 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 // (kernels.hip ft_libm_lds_offset); the lean kernel keeps one row of FT_COOP_SEG floats per wave behind everything (16-byte aligned) for
 // the latency mode (kernels.hip ft_coop_lds_offset)
 #define FT_COOP_SEG_FLOATS 256
-size_t ldsBytes(const ft_scene* s, bool libm = false) {
-    size_t floats = (size_t)FT_LDS_HDR_FLOATS + (size_t)s->dev.nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
+// traceLaunch: the lean trace kernel keeps its accumulator in a register and is launched with nSlots = 0 (launchTrace) — 2 KB per workgroup
+// that decide between 6 and 7 resident workgroups per CU; every other user of a lean scene (ft_eval_distance) runs the general interpreter
+size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false) {
+    const size_t nSlots = (traceLaunch && s->dev.fastPath == 1u) ? 0 : s->dev.nSlots;
+    size_t floats = (size_t)FT_LDS_HDR_FLOATS + nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
     if (libm) floats = ((floats + 1) & ~(size_t)1) + (size_t)FT_LIBM_TAB_DOUBLES * 2;
     if (s->dev.fastPath == 1u) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
     return floats * 4;
@@ -244,7 +247,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     uint32_t* counter = c->dCounter + (lane ? 16 : 0);
     int perCU = 0;
     const bool libm = libmLaunch(c, s);
-    const size_t lds = ldsBytes(s, libm);
+    const size_t lds = ldsBytes(s, libm, true);
     HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, libm, lds, &perCU));
     perCU = std::max(1, std::min(perCU, 8));
     if (c->optMaxBlocksPerCU > 0) perCU = std::min(perCU, c->optMaxBlocksPerCU);       // FT_OPT_MAX_BLOCKS_PER_CU (experiments only)
@@ -272,6 +275,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
+    if (s->dev.fastPath == 1u) a.S.nSlots = 0;             // the lean kernel uses no value slots: its LDS layout has none (ldsBytes)
     a.math = libm ? 1u : 0u;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
     a.materialsExt = s->dMaterialsExt;
