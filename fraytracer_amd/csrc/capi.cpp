@@ -59,7 +59,6 @@ struct ft_ctx {
     int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
     int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
     int optChunk = 64;                                     // FT_OPT_CHUNK: jobs per grab (experiments: 64 = one 8x8 tile, 32, 16)
-    int optWalk = -1;                                      // FT_OPT_WALK: -1 by load, 0 pair walk (throughput build), 1 wide walk (latency build)
     int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
 
@@ -214,8 +213,6 @@ size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false) 
 }
 // Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
 constexpr int FT_TAIL_K_LEAN = 32, FT_TAIL_K_GENERAL = 2;
-// the latency build of the general kernel is taken below this many 8x8 tiles per wave slot of the throughput build (measured: tools/size_probe.py)
-constexpr int FT_WIDE_TILES_PER_SLOT = 4;
 // does this launch take the glibc build of the kernels?
 bool libmLaunch(const ft_ctx* c, const ft_scene* s) { return c->optMath != FT_MATH_FIXED && s->usesExpLog; }
 
@@ -253,18 +250,6 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     const size_t lds = ldsBytes(s, libm, true);
     HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, libm, lds, &perCU));
     perCU = std::max(1, std::min(perCU, 8));
-    // Latency build of the plain general kernel (kernels.hip eval_union_prims_wide): a launch with only a few tiles per resident wave takes as
-    // long as its longest tile, i.e. it is bound by the latency of one wave's rounds, not by throughput.  FT_OPT_WALK: -1 picks by load.
-    a.wide = 0u;
-    if (s->dev.fastPath == 0u && a.ext == 0u && !libm && !s->flat.grids.empty()) {
-        const uint64_t slots = (uint64_t)c->numCUs * perCU * (FT_BLOCK / 64);
-        const bool light = (uint64_t)a.nJobs < (uint64_t)FT_WIDE_TILES_PER_SLOT * 64u * slots;
-        if (c->optWalk == 1 || (c->optWalk < 0 && light)) {
-            a.wide = 1u;
-            HIP_TRY(ft_trace_occupancy_wide(lds, &perCU));
-            perCU = std::max(1, std::min(perCU, 8));
-        }
-    }
     if (c->optMaxBlocksPerCU > 0) perCU = std::min(perCU, c->optMaxBlocksPerCU);       // FT_OPT_MAX_BLOCKS_PER_CU (experiments only)
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
@@ -341,7 +326,6 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_HOST_CHUNKS: if (value < 0 || value > 16) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_CHUNKS: 0 (automatic) .. 16"); c->optHostChunks = value; return FT_OK;
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
     case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
-    case FT_OPT_WALK: if (value < -1 || value > 1) return setErr(FT_ERR_INVALID, "FT_OPT_WALK: -1 (by load), 0 or 1"); c->optWalk = value; return FT_OK;
     case FT_OPT_CHUNK: if (value != 64 && value != 32 && value != 16) return setErr(FT_ERR_INVALID, "FT_OPT_CHUNK: 64, 32 or 16"); c->optChunk = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_MATH:
@@ -361,7 +345,6 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
     case FT_OPT_CHUNK: *value = c->optChunk; return FT_OK;
-    case FT_OPT_WALK: *value = c->optWalk; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
 }

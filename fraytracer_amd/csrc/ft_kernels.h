@@ -39,7 +39,6 @@ struct FtRenderArgs {
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
     uint32_t refillMin;       // idle lanes a wave waits for before it takes new rays (1 = refill at once; kernels.hip "Burst refill")
     uint32_t math;            // 0: the default kernels; 1: launch the *_libm build (FT_OPT_MATH = glibc and the scene has a unionSmooth)
-    uint32_t wide, pad3;      // 1: launch the latency build of the plain general kernel (ft_trace_kernel_wide)
     uint32_t shrink1, shrink2;   // guided hand-out: from job shrink1 on a wave takes chunk / 2 jobs at a time, from shrink2 on chunk / 4 (nJobs: never)
     uint32_t tailK;           // latency mode: a wave holding at most this many rays evaluates them one at a time with all 64 lanes (0 = off)
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
@@ -78,7 +77,6 @@ hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_
 hipError_t ft_launch_deinterleave(const float* recv, float* frame, unsigned long long stripeFloats, uint32_t nStripes, uint32_t nRanks, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
 hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU);
-hipError_t ft_trace_occupancy_wide(size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus
 }
 #endif

@@ -500,89 +500,9 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     outD = mn; outLeaf = leaf;
 }
 
-#ifndef FT_WIDE
-#define FT_WIDE 8             // candidates per trip of the latency build
-#endif
-#ifndef FT_WIDE_WAVES
-#define FT_WIDE_WAVES 4       // its waves per SIMD (128 VGPRs)
-#endif
-// The LATENCY build of the walk (ft_trace_kernel_wide: frames with only a few tiles per resident wave, e.g. the reference's own 1000 x 1000).
-// Such a frame takes as long as its longest tile — a 64 x 64 crop of the Program.fs scene needs 1.28 ms against 2.2 ms for the whole frame —
-// i.e. (rounds of that tile) x (latency of one round of a wave that has the SIMD to itself), and that latency is the walk's chain of dependent
-// trips: ~13 x (records' round trip + tests).  Here a trip requests the records of W candidates at once and computes all their right-hand sides
-// side by side; the decisions are then taken in list order by a scan — the first candidate from k0 on that either fails :30 (the walk ends) or
-// passes :30 and :31 (it is evaluated, in ONE place, and the scan resumes behind it with the new minimum; a candidate the scan passed over had
-// failed :31 against the same minimum the reference would have held at that point).  Same tests, same order, same evaluations as the pair walk;
-// more wasted tests behind the break (at most W - 1 per evaluation) and W x 7 registers of records, which only a lightly loaded GPU can afford.
-template <bool FQ, int W>
-__device__ __forceinline__ void eval_union_prims_wide(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
-                                                      const float* __restrict__ sd, const uint32_t* __restrict__ sl,
-                                                      float& outD, uint32_t& outLeaf) {
-    const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
-    const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
-    const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
-    const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
-    const uint32_t cell = g.cellBase + (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz);
-    cfp ctr = as_const(S.cellCenters) + 3u * cell;
-    const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
-    const uint32_t FT_CONST* cellStart = as_const(S.cellStart);
-    const FtItemRec FT_CONST* items = as_const(S.items);
-    cfp consts = as_const(S.consts);
-    uint32_t i = cellStart[cell];
-    const uint32_t end = cellStart[cell + 1];
-    float mn = 0.0f; uint32_t leaf = 0;
-    bool first = true;
-    for (;;) {
-        const uint32_t n = end - i;                                    // candidates left, this group included (>= 1)
-        float lb[W], md[W];
-        uint32_t td[W], mt[W];
-        {
-            ItemRegs r[W];
-#pragma unroll
-            for (int k = 0; k < W; ++k) r[k] = ld_item_at(items, (uint32_t)k < n ? i + (uint32_t)k : end - 1u);
-#pragma unroll
-            for (int k = 0; k < W; ++k) asm volatile("" : "+v"(r[k].a), "+v"(r[k].b));          // every record is requested before any is waited for
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                lb[k] = r[k].a.x - distanceToCenter;                                             // :30 right-hand side
-                md[k] = ft_dist<FQ>(mk3(r[k].a.y, r[k].a.z, r[k].a.w), p) - __uint_as_float(r[k].b.x);   // :31 getMinDistance
-                td[k] = r[k].b.y; mt[k] = r[k].b.z;
-            }
-        }
-        uint32_t k0 = 0;
-        bool stop = false;
-        for (;;) {
-            uint32_t sel = (uint32_t)W, tdS = 0, mtS = 0;
-            bool fail = false;
-#pragma unroll
-            for (int k = W - 1; k >= 0; --k) {                         // the lowest k that decides anything wins
-                const bool isFirst = first && k == 0;                  // Items.[0]: evaluated unconditionally (:26)
-                const bool fail30 = !isFirst && !(mn > lb[k]);
-                const bool pass = isFirst || (mn > lb[k] && mn > md[k]);
-                if ((uint32_t)k >= k0 && (uint32_t)k < n && (fail30 || pass)) { sel = (uint32_t)k; fail = fail30; tdS = td[k]; mtS = mt[k]; }
-            }
-            if (sel == (uint32_t)W) break;                             // nothing left to decide in this group
-            if (fail) { stop = true; break; }                          // :30 false for this and every later candidate (sorted list)
-            const uint32_t type = tdS & 15u, data = tdS >> 4;
-            float d; uint32_t l;
-            if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
-            else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p); l = mtS; }
-            if (first) { mn = d; leaf = l; first = false; }
-            else {
-                if (d < mn) leaf = l;                                  // SdfObject.fs:41-43
-                mn = ft_min(mn, d);                                    // SdfForm.fs:33
-            }
-            k0 = sel + 1u;
-        }
-        if (stop || n <= (uint32_t)W) break;
-        i += (uint32_t)W;
-    }
-    outD = mn; outLeaf = leaf;
-}
-
 // the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
-template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false, int WALK = 0>
+template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
                                         uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk);
 
@@ -724,7 +644,7 @@ __device__ __forceinline__ void eval_union_coop(const FtSceneDev& S, const FtGri
     outD = mn; outLeaf = leaf;
 }
 
-template <bool WITH_UNION, bool CALLS, int MATH, bool COOP, int WALK>
+template <bool WITH_UNION, bool CALLS, int MATH, bool COOP>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
                                         uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk) {
     cfp consts = as_const(S.consts);
@@ -791,9 +711,6 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
                 if constexpr (CALLS) {                                 // scenes with sub-program children (FtSceneDev.fastPath == 2)
                     if (fastOk && S.fastQ) eval_union<true, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                     else eval_union<false, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
-                } else if constexpr (WALK == 1) {                      // latency build: FT_WIDE candidates per trip
-                    if (fastOk && S.fastQ) eval_union_prims_wide<true, FT_WIDE>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
-                    else eval_union_prims_wide<false, FT_WIDE>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
                 } else {
                     if (fastOk && S.fastQ) eval_union_prims<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
                     else eval_union_prims<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
@@ -807,12 +724,12 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
     }
 }
 
-template <bool CALLS, int MATH, int WALK = 0>
+template <bool CALLS, int MATH>
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
                                         const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
     const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
     const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    ft_exec<true, CALLS, MATH, false, WALK>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
+    ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -1208,7 +1125,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return x;
 }
 
-template <int VARIANT, bool EXT, int MATH = 0, int WALK = 0>
+template <int VARIANT, bool EXT, int MATH = 0>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the first wave of block 0 reports the shader clock it ran at (statistics only); its start clocks wait in LDS, not in registers
@@ -1323,7 +1240,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             else {
                 const f3 q = query_point();
                 if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf);
-                else ft_eval<VARIANT == 2, MATH, WALK>(a.S, q, sd, sl, ldsC, d, leaf);
+                else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
             }
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
@@ -1436,8 +1353,6 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_sp
 // general scenes whose unions have combinator children evaluated on demand (FT_PR_CALL, FtSceneDev.fastPath == 2)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_CALLS_OCC ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
-// latency build of the plain general kernel (eval_union_prims_wide): picked by the host for launches with few tiles per resident wave
-extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_OCC(FT_WIDE_WAVES) ft_trace_kernel_wide(const FtRenderArgs a) { ft_trace_body<0, false, 0, 1>(a); }
 // FT_OPT_MATH = glibc: the same six with MathF.Exp / Log as glibc's expf / logf (scenes that contain a unionSmooth only; every other scene
 // has no exponential and runs the kernels above whatever the option says)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_libm(const FtRenderArgs a) { ft_trace_body<0, false, 1>(a); }
@@ -1774,12 +1689,8 @@ extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, si
     else if (v == 2 && ext) hipLaunchKernelGGL(ft_trace_kernel_calls_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (v == 2) hipLaunchKernelGGL(ft_trace_kernel_calls, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (ext) hipLaunchKernelGGL(ft_trace_kernel_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
-    else if (a->wide) hipLaunchKernelGGL(ft_trace_kernel_wide, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else hipLaunchKernelGGL(ft_trace_kernel, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     return hipGetLastError();
-}
-extern "C" hipError_t ft_trace_occupancy_wide(size_t ldsBytes, int* blocksPerCU) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, (const void*)ft_trace_kernel_wide, FT_BLOCK, ldsBytes);
 }
 extern "C" hipError_t ft_launch_eval_points(const FtSceneDev* S, int math, const float* pts, long long n, float* outD, int* outM,
                                             unsigned blocks, size_t ldsBytes, hipStream_t st) {

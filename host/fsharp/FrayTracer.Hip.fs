@@ -63,7 +63,7 @@ module Native =
     [<DllImport(Lib)>] extern int ft_abi_version()
     [<DllImport(Lib)>] extern nativeint ft_build_info()
     [<DllImport(Lib)>] extern int ft_ctx_create(int device, nativeint& ctx)
-    // per-context switches (ft_option: 1 refill_min, 2 max_blocks_per_cu, 3 host_chunks, 4 host_pin, 5 tail_k, 6 math, 7 guided, 8 chunk, 9 walk); the library reads no environment
+    // per-context switches (ft_option: 1 refill_min, 2 max_blocks_per_cu, 3 host_chunks, 4 host_pin, 5 tail_k, 6 math, 7 guided, 8 chunk); the library reads no environment
     [<DllImport(Lib)>] extern int ft_ctx_set_option(nativeint ctx, int option, int value)
     [<DllImport(Lib)>] extern void ft_ctx_destroy(nativeint ctx)
     [<DllImport(Lib)>] extern nativeint ft_last_error()

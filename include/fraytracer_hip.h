@@ -116,8 +116,6 @@ typedef enum ft_option {
     FT_OPT_TAIL_K = 5,            /* latency mode: a wave holding at most this many rays evaluates them one at a time with all 64 lanes;
                                    * -1 (default) = the kernel's own threshold, 0 = off, 1..64 */
     FT_OPT_MATH = 6,              /* ft_math_mode (below); default FT_MATH_FIXED */
-    FT_OPT_WALK = 9,              /* grid-union walk of the plain general kernel: -1 (default) by load — the latency build (8 candidates per trip) for launches
-                                   * with few tiles per resident wave, the throughput build (2 per trip) otherwise; 0 / 1 force one */
     FT_OPT_CHUNK = 8,             /* 64 (default): rays a wave takes per grab = one 8x8 tile; 32 / 16: half / quarter tiles (experiments) */
     FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;

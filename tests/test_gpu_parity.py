@@ -266,43 +266,6 @@ def test_latency_mode_is_bit_identical(gpu, oracle, k):
         gpu.set_option("tail_k", -1)
 
 
-@pytest.mark.parametrize("walk", [0, 1])
-def test_latency_build_of_the_union_walk_is_bit_identical(gpu, oracle, walk):
-    """FT_OPT_WALK: the plain general kernel exists twice — the throughput build (two candidates per trip) and the latency build
-    (eight per trip, decisions by an in-order scan, ft_trace_kernel_wide) the host picks for launches with few tiles per resident
-    wave.  Forced either way: images, counters and flags are the oracle's on every union scene class, lists shorter and longer than
-    one trip, slots, every primitive kind, NaN rays through triangles, and in combination with the latency mode's thresholds."""
-    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
-    cam = syn.default_camera()
-    gpu.set_option("walk", walk)
-    try:
-        for tail_k in (-1, 0, 64):
-            gpu.set_option("tail_k", tail_k)
-            cases = [("C2", syn.config2(seed=6, size=96)[0], 96), ("C2 boxes", syn.config2(boxes=True, size=64)[0], 64), ("console-like 300", syn.console_like(n=300)[0], 96),
-                     ("mixed nested", syn.mixed_nested()[0], 96), ("combinator zoo", syn.combinator_zoo()[0], 80)] + \
-                    [(f.__name__, syn.console_like(n=40, factory=f)[0], 64) for f in (syn.random_sphere, syn.random_capsule, syn.random_torus, syn.random_triangle, syn.random_box)]
-            if tail_k != -1: cases = cases[:4]
-            for name, scene, n in cases:
-                ds, os_ = both(gpu, oracle, scene)
-                assert ds.info()["fast_path"] == 0
-                g, gst = ds.render(EPS, LEN, ft.ImageSize(n, n), cam)
-                o, ocnt = os_.render(EPS, LEN, n, n, cam.as_array())
-                assert_bit_equal(g, o, f"{name}, walk = {walk}, tail_k = {tail_k}")
-                check_counts(gst, ocnt)
-        gpu.set_option("tail_k", -1)
-        tri = lambda t: SdfForm.Primitive.triangle((-1 + t, -1, 0), (1 + t, -1, 0.2), (0 + t, 1, -0.1), 0.2)
-        mat = SdfMaterial.createSolid((0.3, 0.6, 0.9))
-        nan_rays = np.array([[0, 0, -5, 0, 0, 1, 30, 0.01], [0, 0, -5, np.nan, 0, 1, 30, 0.01], [0.1, 0, -5, 0, np.nan, np.nan, 30, 0.01]], np.float32)
-        sc = SdfScene(SdfObject.union([SdfObject.create(mat, tri(0)), SdfObject.create(mat, tri(0.5)), SdfObject.create(mat, tri(-0.5))]), syn.BACKGROUND, syn.program_lights())
-        dsn, osn = both(gpu, oracle, sc)
-        gr, gst = dsn.trace_rays(nan_rays)
-        orr, ocnt = osn.trace_rays(nan_rays)
-        assert_bit_equal(gr, orr, "NaN rays"); assert gst["flags"] == ocnt["flags"] == 3
-        d, m = dsn.eval_distance(np.random.default_rng(3).uniform(-3, 3, (500, 3)).astype(np.float32))
-    finally:
-        gpu.set_option("walk", -1); gpu.set_option("tail_k", -1)
-
-
 def test_hand_out_options_do_not_change_the_frame(gpu, oracle):
     """FT_OPT_CHUNK (rays per grab: whole, half, quarter tiles) and FT_OPT_GUIDED (shrinking grabs at the end of the queue) only change which
     wave renders which pixel: the frame and the counters stay those of the oracle"""
