@@ -212,7 +212,7 @@ size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false) 
     return floats * 4;
 }
 // Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
-constexpr int FT_TAIL_K_LEAN = 32, FT_TAIL_K_GENERAL = 16, FT_TAIL_K_CALLS = 2, FT_TAIL_SERIAL = 2;
+constexpr int FT_TAIL_K_LEAN = 32, FT_TAIL_K_GENERAL = 2;
 // does this launch take the glibc build of the kernels?
 bool libmLaunch(const ft_ctx* c, const ft_scene* s) { return c->optMath != FT_MATH_FIXED && s->usesExpLog; }
 
@@ -263,8 +263,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     // glass config 39.1 / 31.5 / 27.3, and even the VALU-bound C3 kernel 61.0 / 66.5 / 60.3: rays that start together stay in
     // step (march, the four normal probes, shadow rays), so a wave's lanes share lookup cells, list positions and branches.
     a.refillMin = (uint32_t)c->optRefillMin;               // 64 unless FT_OPT_REFILL_MIN says otherwise (experiments)
-    a.tailK = (uint32_t)(c->optTailK >= 0 ? c->optTailK : (s->dev.fastPath == 1u ? FT_TAIL_K_LEAN : (s->dev.fastPath == 2u ? FT_TAIL_K_CALLS : FT_TAIL_K_GENERAL)));
-    a.tailSerial = (uint32_t)FT_TAIL_SERIAL;
+    a.tailK = (uint32_t)(c->optTailK >= 0 ? c->optTailK : (s->dev.fastPath == 1u ? FT_TAIL_K_LEAN : FT_TAIL_K_GENERAL));
     // guided hand-out of the last jobs (kernels.hip refill): one half tile, then one quarter tile per resident wave — only where the latency
     // mode makes a part-filled wave cheap (lean kernel, tailK >= 32) and only for the reference's sampling (tile-major job order)
     a.shrink1 = a.shrink2 = a.nJobs;

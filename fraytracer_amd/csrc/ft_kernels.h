@@ -39,9 +39,7 @@ struct FtRenderArgs {
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
     uint32_t refillMin;       // idle lanes a wave waits for before it takes new rays (1 = refill at once; kernels.hip "Burst refill")
     uint32_t math;            // 0: the default kernels; 1: launch the *_libm build (FT_OPT_MATH = glibc and the scene has a unionSmooth)
-    uint32_t pad2;
     uint32_t shrink1, shrink2;   // guided hand-out: from job shrink1 on a wave takes chunk / 2 jobs at a time, from shrink2 on chunk / 4 (nJobs: never)
-    uint32_t tailSerial;      // general kernels: up to this many rays are evaluated one after the other (all 64 lanes each), more share the wave
     uint32_t tailK;           // latency mode: a wave holding at most this many rays evaluates them one at a time with all 64 lanes (0 = off)
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move

@@ -182,12 +182,11 @@ template <bool FQ> __device__ __forceinline__ float prim_torus(cfp c, f3 p) {
     return ft_sq<FQ>(distanceToPlane * distanceToPlane + distanceToCircle * distanceToCircle) - c[7];   // :194
 }
 
-// `defer`: a speculative evaluation (eval_union_packed) must not raise the flag itself — the caller does, if the reference evaluates the candidate
-template <bool FQ> __device__ __forceinline__ float prim_triangle(cfp c, f3 p, uint32_t* defer = nullptr) {
+template <bool FQ> __device__ __forceinline__ float prim_triangle(cfp c, f3 p) {
     const f3 p1 = p - ld3(c), p2 = p - ld3(c + 4), p3 = p - ld3(c + 8);   // :228-230
     float distance;
     const float e1 = ft_dot(ld3(c + 40), p1), e2 = ft_dot(ld3(c + 44), p2), e3 = ft_dot(ld3(c + 48), p3);
-    if (e1 != e1 || e2 != e2 || e3 != e3) { if (defer) *defer |= 2u; else ft_flag(2u); }   // MathF.Sign(NaN) throws in .NET (Math.fs:40): flag bit 1, sign taken as 0
+    if (e1 != e1 || e2 != e2 || e3 != e3) ft_flag(2u);                 // MathF.Sign(NaN) throws in .NET (Math.fs:40): flag bit 1, sign taken as 0
     const int s = ft_sign_i(e1) + ft_sign_i(e2) + ft_sign_i(e3);
     if (s < 2) {                                                       // :235-237
         const f3 v21 = ld3(c + 12), v32 = ld3(c + 16), v13 = ld3(c + 20);
@@ -208,12 +207,12 @@ __device__ __forceinline__ float prim_box(cfp c, f3 p) {   // EXTENSION (always 
     return ft_length(qp) + ft_min(ft_max(q.x, ft_max(q.y, q.z)), 0.0f);
 }
 
-template <bool FQ> __device__ __forceinline__ float prim_eval_t(uint32_t type, cfp c, f3 p, uint32_t* defer = nullptr) {
+template <bool FQ> __device__ __forceinline__ float prim_eval_t(uint32_t type, cfp c, f3 p) {
     switch (type) {
         case FT_PR_SPHERE: return prim_sphere<FQ>(c, p);
         case FT_PR_CAPSULE: return prim_capsule<FQ>(c, p);
         case FT_PR_TORUS: return prim_torus<FQ>(c, p);
-        case FT_PR_TRIANGLE: return prim_triangle<FQ>(c, p, defer);
+        case FT_PR_TRIANGLE: return prim_triangle<FQ>(c, p);
         default: return prim_box(c, p);
     }
 }
@@ -503,10 +502,9 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
 
 // the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
-struct FtGroup;
-template <bool WITH_UNION, bool CALLS, int MATH, int COOP = 0>
+template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
-                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, const FtGroup* grp = nullptr);
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk);
 
 template <bool FQ, int MATH>
 __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
@@ -576,73 +574,6 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
 // word s*FT_BLOCK + t: conflict-free).  Returns scene.Object.Form.Distance(p) and the material
 // the reference's material closure would pick at p.
 // ------------------------------------------------------------------------------------------------
-// Latency mode, 3 to 16 rays (plain general kernels): the rays share the wave, 2^lg = 64 / (rays rounded up to a power of two) lanes each.  `p` is the
-// point of the lane's group, `valid` whether the group serves a ray.  Every lane evaluates Items.[0] of its cell (SdfForm.fs:26); then, 2^lg
-// candidates at a time, lane k of a group loads record k of the group's list, computes the right-hand sides of :30 / :31 and — where the candidate
-// can still pass them against the minimum the trip starts with (the minimum only falls) — its Distance, SPECULATIVELY; the group then replays the
-// reference's loop over its 2^lg positions in list order (values passed through ds_bpermute): :30 against the current minimum (fails -> the walk
-// ends: sorted list), :31, and where the reference evaluates the candidate its speculative value enters Min / the strict '<' of the material pick,
-// and only then is a MathF.Sign(NaN) the evaluation met reported.  Same tests, same order, same values as eval_union_prims; a round costs about
-// 60 % of a one-ray-per-lane round's sequential instructions at 4 lanes per ray and 40 % at 16, which is what a nearly empty wave's time is made of.
-struct FtGroup { uint32_t lg; bool valid; };
-template <bool FQ>
-__device__ __forceinline__ void eval_union_packed(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p, const FtGroup grp,
-                                                  const float* __restrict__ sd, const uint32_t* __restrict__ sl, float& outD, uint32_t& outLeaf) {
-    const uint32_t lane = threadIdx.x & 63u, gsize = 1u << grp.lg, k = lane & (gsize - 1u), gbase = lane & ~(gsize - 1u);
-    const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
-    const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
-    const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
-    const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
-    const uint32_t cell = g.cellBase + (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz);
-    cfp ctr = as_const(S.cellCenters) + 3u * cell;
-    const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);          // SdfForm.fs:25
-    const uint32_t FT_CONST* cellStart = as_const(S.cellStart);
-    const FtItemRec FT_CONST* items = as_const(S.items);
-    cfp consts = as_const(S.consts);
-    const uint32_t first = cellStart[cell], end = cellStart[cell + 1];
-    uint32_t raised = 0;                                               // flags of the evaluations the reference performs (this lane's view; the group agrees)
-    auto evaluate = [&](uint32_t typeData, uint32_t mat, float& d, uint32_t& l, uint32_t& fl) {
-        const uint32_t type = typeData & 15u, data = typeData >> 4;
-        if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
-        else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p, &fl); l = mat; }
-    };
-    float mn; uint32_t leaf;
-    {
-        const ItemRegs r0 = ld_item_at(items, first);                  // Items.[0]: unconditional (:26)
-        uint32_t fl = 0;
-        evaluate(r0.b.y, r0.b.z, mn, leaf, fl);
-        raised |= fl;
-    }
-    bool done = !grp.valid;
-    for (uint32_t base = first + 1u; __ballot(!done) != 0ull; base += gsize) {
-        const uint32_t idx = base + k;
-        const bool have = !done && idx < end;
-        const ItemRegs r = ld_item_at(items, have ? idx : first);
-        const float lb = r.a.x - distanceToCenter;                                      // :30 right-hand side
-        const float md = ft_dist<FQ>(mk3(r.a.y, r.a.z, r.a.w), p) - __uint_as_float(r.b.x);   // :31 getMinDistance
-        float d = 0.0f; uint32_t l = 0, fl = 0;
-        if (have && mn > lb && mn > md) evaluate(r.b.y, r.b.z, d, l, fl);               // can still pass: speculative Distance
-        const uint32_t bits = (have ? 1u : 0u) | (fl << 1);
-        for (uint32_t t = 0; t < gsize; ++t) {                                          // the reference's loop over this trip's candidates, in list order
-            const int src = (int)(gbase + t);
-            const uint32_t bT = (uint32_t)__shfl((int)bits, src, 64);
-            const float lbT = __shfl(lb, src, 64), mdT = __shfl(md, src, 64), dT = __shfl(d, src, 64);
-            const uint32_t lT = (uint32_t)__shfl((int)l, src, 64);
-            if (!done && (bT & 1u)) {
-                if (!(mn > lbT)) done = true;                                           // :30 false for this and every later candidate
-                else if (mn > mdT) {                                                    // :31 -> the reference calls the candidate's Distance (:33)
-                    if (dT < mn) leaf = lT;                                             // SdfObject.fs:41-43
-                    mn = ft_min(mn, dT);                                                // SdfForm.fs:33
-                    raised |= bT >> 1;
-                }
-            }
-        }
-        if (base + gsize >= end) done = true;                                           // the list is exhausted
-    }
-    if (grp.valid && (raised & 2u)) ft_flag(2u);
-    outD = mn; outLeaf = leaf;
-}
-
 // Latency mode (see "Latency (tail) mode" below): the grid union of ONE query point, the same in all 64 lanes.  Items.[0] is evaluated by
 // every lane (SdfForm.fs:26).  Then, 64 candidates at a time, lane j loads record j of the cell's list and computes the right-hand sides of
 // the two pruning tests (:30 LowerBound - distanceToCenter, :31 getMinDistance) — they do not depend on the running minimum — and the wave
@@ -713,9 +644,9 @@ __device__ __forceinline__ void eval_union_coop(const FtSceneDev& S, const FtGri
     outD = mn; outLeaf = leaf;
 }
 
-template <bool WITH_UNION, bool CALLS, int MATH, int COOP>
+template <bool WITH_UNION, bool CALLS, int MATH, bool COOP>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
-                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, const FtGroup* grp) {
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk) {
     cfp consts = as_const(S.consts);
     for (; pc < pcEnd; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
@@ -773,11 +704,7 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
         case FT_OP_UNION: {
             if constexpr (WITH_UNION) {
                 float d; uint32_t l;
-                if constexpr (COOP == 2) {                             // latency mode, several rays: 64 / rays lanes each
-                    if (fastOk && S.fastQ) eval_union_packed<true>(S, as_const(S.grids)[in.aux], p, *grp, sd, sl, d, l);
-                    else eval_union_packed<false>(S, as_const(S.grids)[in.aux], p, *grp, sd, sl, d, l);
-                } else
-                if constexpr (COOP == 1) {                             // latency mode: one point, candidates across the lanes
+                if constexpr (COOP) {                                  // latency mode: one point, candidates across the lanes
                     if (fastOk && S.fastQ) eval_union_coop<true, CALLS, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                     else eval_union_coop<false, CALLS, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                 } else
@@ -814,17 +741,7 @@ __device__ __forceinline__ void ft_eval_coop(const FtSceneDev& S, const f3 p, fl
                                              const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
     const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
     const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    ft_exec<true, CALLS, MATH, 1>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
-    outD = sd[0];
-    outLeaf = sl[0];
-}
-// latency mode, several rays: every lane runs the program on the point of its group; the grid union is shared by the group's lanes
-template <int MATH>
-__device__ __forceinline__ void ft_eval_packed(const FtSceneDev& S, const f3 p, const FtGroup grp, float* __restrict__ sd, uint32_t* __restrict__ sl,
-                                               const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
-    const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
-    const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    ft_exec<true, false, MATH, 2>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk, &grp);
+    ft_exec<true, CALLS, MATH, true>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -1303,25 +1220,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             if (VARIANT == 1) {                                        // smooth union of spheres: all the rays at once, 64 / rays lanes each
                 ft_eval_smooth_spheres_packed<MATH>(a.S, qm, active, am, (uint32_t)__popcll(am), ldsC, coopRow, dCoop, leafCoop);
                 coopEvals += (uint32_t)__popcll(am);
-            } else if (VARIANT == 0 && (uint32_t)__popcll(am) > a.tailSerial) {   // plain general kernels, 3 .. 16 rays: 64 / rays lanes each
-                const uint32_t n = (uint32_t)__popcll(am);
-                const uint32_t lg = 6u - (32u - (uint32_t)__builtin_clz(n - 1u));
-                const uint32_t G = lane >> lg;
-                int src = 0;                                           // the lane that holds the ray of rank G
-                {
-                    unsigned long long m = am;
-                    for (uint32_t r = 0; r < n; ++r) { const int L = __ffsll((long long)m) - 1; m &= m - 1ull; if (r == G) src = L; }
-                }
-                FtGroup grp; grp.lg = lg; grp.valid = G < n;
-                f3 pG = mk3(__shfl(qm.x, src, 64), __shfl(qm.y, src, 64), __shfl(qm.z, src, 64));
-                if (!grp.valid) pG = mk3(0.0f, 0.0f, 0.0f);            // lanes of unused groups: any harmless point
-                float dG; uint32_t leafG;
-                ft_eval_packed<MATH>(a.S, pG, grp, sd, sl, ldsC, dG, leafG);
-                const uint32_t rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-                dCoop = __shfl(dG, (int)(rank << lg), 64);
-                leafCoop = (uint32_t)__shfl((int)leafG, (int)(rank << lg), 64);
-                coopEvals += n;
-            } else {                                                   // one ray after the other, all 64 lanes each
+            } else {                                                   // general scenes: one ray after the other, all 64 lanes each
                 unsigned long long m = am;
                 while (m != 0ull) {
                     const int L = __ffsll((long long)m) - 1;
