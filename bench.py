@@ -360,7 +360,7 @@ def main():
         # roofline of the dominant (only) kernel, from this rank's launches: algorithmic lane-ops per
         # launch / mean HIP-event duration of a launch
         build = ft.build_info()
-        traffic, traffic_src, valu_busy = profile_figures(build["src"], "ft_trace_kernel_smooth_spheres  ") if (W == 4096 and world == 1) else (None, None, None)
+        traffic, traffic_src, valu_busy = profile_figures(build["src"], "ft_trace_kernel_smooth_spheres ") if (W == 4096 and world == 1) else (None, None, None)
         if traffic_src is None:
             traffic_src = "no profiles/*_summary.txt carries the stamp of this build (src=%s): traffic / valu_busy_pmc not quoted" % build["src"]
         flops_launch = algorithmic_flops(st, args.spheres) / args.steps

@@ -72,7 +72,11 @@ def test_the_library_reads_no_environment_variables():
         assert host.get_option("refill_min") == 64 and host.get_option("host_pin") == 1
         host.set_option("refill_min", 32); host.set_option("host_chunks", 2); host.set_option("host_pin", 0); host.set_option("max_blocks_per_cu", 3)
         assert [host.get_option(k) for k in ("refill_min", "host_chunks", "host_pin", "max_blocks_per_cu")] == [32, 2, 0, 3]
-        for name, bad in (("refill_min", 0), ("refill_min", 65), ("host_chunks", 17), ("host_pin", 2), ("max_blocks_per_cu", -1)):
+        assert [host.get_option(k) for k in ("math", "tail_k", "guided", "chunk")] == [0, -1, 0, 64]
+        host.set_option("math", 2); host.set_option("tail_k", 8); host.set_option("guided", 1); host.set_option("chunk", 16)
+        assert [host.get_option(k) for k in ("math", "tail_k", "guided", "chunk")] == [2, 8, 1, 16]
+        for name, bad in (("refill_min", 0), ("refill_min", 65), ("host_chunks", 17), ("host_pin", 2), ("max_blocks_per_cu", -1),
+                          ("math", 3), ("tail_k", 65), ("tail_k", -2), ("guided", 2), ("chunk", 48)):
             try:
                 host.set_option(name, bad)
             except ft.FrayTracerError as e:
