@@ -31,8 +31,15 @@ struct FColor { Vector3 v; static FColor ofRGB(float r, float g, float b) { retu
 
 class Context {                                   // one per GPU (device -1: construction only)
 public:
-    explicit Context(int device = 0) { check(ft_ctx_create(device, &ctx_)); }
+    explicit Context(int device = 0) {
+        if (ft_abi_version() != FT_ABI_VERSION) throw std::runtime_error("libfraytracer_hip: ABI version mismatch (header vs library)");
+        check(ft_ctx_create(device, &ctx_));
+    }
     ~Context() { ft_ctx_destroy(ctx_); }
+    // per-context switches (ft_option); e.g. setOption(FT_OPT_MATH, FT_MATH_GLIBC_FMA): MathF.Exp / Log / Pow as this host's glibc computes them
+    void setOption(ft_option option, int value) { check(ft_ctx_set_option(ctx_, (int32_t)option, value)); }
+    int getOption(ft_option option) const { int32_t v = 0; check(ft_ctx_get_option(ctx_, (int32_t)option, &v)); return v; }
+    static std::string buildInfo() { return ft_build_info(); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     ft_ctx* get() const { return ctx_; }

@@ -148,6 +148,44 @@ def test_glibc_restatement_on_the_device(gpu, oracle):
         assert np.array_equal(np.isnan(e), np.isnan(o)); assert_bit_equal(np.nan_to_num(e, nan=0.0), np.nan_to_num(o, nan=0.0), "powf")
 
 
+def test_glibc_sse2_build_on_the_device_in_a_child_process():
+    """The OTHER glibc build.  A child process started under GLIBC_TUNABLES=glibc.cpu.hwcaps=-FMA,-AVX2 has a libm that resolves
+    expf / logf / powf to their SSE2 builds; there FT_MATH_GLIBC_SSE2 must equal it: all 256 checksum chunks (every float) per function,
+    and a C3 frame against the oracle calling that libm — so both variants of the device restatement are proved on the GPU, whichever
+    CPU the box has."""
+    import os, subprocess, sys
+    if ft.glibc_build_of_this_host() != 1:
+        pytest.skip("this CPU has no FMA / AVX2: the SSE2 build is what the other tests already ran against")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import fraytracer_amd as ft
+from fraytracer_amd import synthetic as syn
+from oracle import binding as ob
+assert ft.glibc_build_of_this_host() == 2
+dev = ft.Device(0)
+y = float(np.float32(1.0) / np.float32(2.2))
+nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+for op, yy in ((0, 0.0), (1, 0.0), (2, y)):
+    want = ob.libm_checksums(op, yy, 0, 256, nthreads)
+    got = dev.selftest_libm(op, 2, yy, 0, 256)
+    assert (want == got).all(), (op, np.nonzero(want != got)[0][:8])
+assert not (dev.selftest_libm(0, 1, 0.0, 0, 256) == ob.libm_checksums(0, 0.0, 0, 256, nthreads)).all()     # the FMA variant is not this libm
+scene, _ = syn.config3(n=256, size=96)
+cam = syn.default_camera()
+dev.set_option("math", 2); ob.lib.orc_set_libm(1)
+g, gst = dev.scene(scene).render(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(96, 96), cam)
+o, ocnt = ob.Oracle().scene(scene).render(syn.EPSILON, syn.RAY_LENGTH, 96, 96, cam.as_array())
+assert np.array_equal(g.view(np.uint32), o.view(np.uint32)) and gst["rays_shadow"] == ocnt["rays_shadow"]
+print("SSE2-OK")
+""" % root
+    env = dict(os.environ, GLIBC_TUNABLES="glibc.cpu.hwcaps=-FMA,-AVX2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SSE2-OK" in out.stdout, out.stderr[-2000:]
+
+
 def test_glibc_math_mode_renders_what_the_oracle_renders_with_libm(gpu, oracle, glibc_mode):
     """FT_OPT_MATH = glibc: SdfForm.unionSmooth's MathF.Exp / MathF.Log (SdfForm.fs:80,82) as this host's C runtime computes them.
     The oracle calls the real expf / logf (orc_set_libm); the kernels run the restatement: bit-exact images and exact counters for
