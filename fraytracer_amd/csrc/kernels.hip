@@ -1168,10 +1168,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             if ((uint32_t)__popcll(idle) < a.refillMin && __ballot(s.phase >= PH_MARCH) != 0ull) break;
             if (chunkNext == chunkEnd) {
                 if (exhausted) break;
-                // Guided hand-out at the end of the queue (lean kernel; everywhere else shrink1 = shrink2 = nJobs): from job shrink1 on a wave
-                // takes half a tile, from shrink2 on a quarter — the latency mode evaluates 32 / 16 rays with 2 / 4 lanes each at 60 % / 33 %
-                // of a full round's cost, so the last generation of work is spread over 2 - 4 times as many waves and drains that much
-                // sooner.  The cursor is read first to pick the size (one more global access per tile: ~0.1 % of a tile's time).
+                // Guided hand-out at the end of the queue (FT_OPT_GUIDED, lean kernel, OFF by default; everywhere else shrink1 = shrink2 = nJobs):
+                // from job shrink1 on a wave takes half a tile, from shrink2 on a quarter, so that the last generation of work is spread over
+                // 2 - 4 times as many waves.  Measured: the 32 / 16-ray rounds of the latency mode cost +34 % / +46 % per ray, more than the
+                // shorter drain returns (N = 8 share of C3 8.67 -> 9.13 ms).  The cursor is read first to pick the size.
                 uint32_t base = 0, take = a.chunk;
                 if (lane == 0) {
                     if (a.shrink1 < a.nJobs) {
