@@ -2,7 +2,10 @@
 """The reference's console program (src/FrayTracer.Console/Program.fs) on the MI355X path:
 System.Random(19) scene of 1000 tori, 1000x1000, epsilon 0.01, ray length 30, timing line, result.bmp.
 
-    python examples/console.py [--size 1000] [--tori 1000] [--out result.bmp]
+    python examples/console.py [--size 1000] [--tori 1000] [--out result.bmp] [--math glibc]
+
+--math glibc: MathF.Pow of the tone map (and MathF.Exp / Log of any unionSmooth) as this host's C runtime computes them — what the reference's
+CPU path returns on this machine under .NET (FT_OPT_MATH); the default is the library's fixed arithmetic.
 """
 import argparse
 import os
@@ -19,7 +22,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1000)
 ap.add_argument("--tori", type=int, default=1000)
 ap.add_argument("--out", default="result.bmp")
+ap.add_argument("--math", choices=("fixed", "glibc"), default="fixed")
 args = ap.parse_args()
+if args.math == "glibc":
+    ft.Device.default(0).set_option("math", ft.glibc_build_of_this_host())
 
 scene, _ = syn.console_scene(seed=19, n=args.tori, size=args.size)        # Program.fs:14-83
 camera = syn.default_camera()                                              # Program.fs:16-22
