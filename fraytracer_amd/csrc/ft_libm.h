@@ -75,17 +75,10 @@ template <bool FMA> FT_HD double ft_mad(double a, double b, double c) { return F
 
 // ---- expf (e_expf.c) --------------------------------------------------------------------------------------------------
 // tab: FT_LIBM_TAB (the 2^(i/32) entries are read as 64-bit patterns)
-template <bool FMA> FT_HD float ft_glibc_expf(float x, const ft_u64* tab) {
+// ft_glibc_expf_main: the function's main path, for callers that have established |x| < 88 (no special case can apply)
+template <bool FMA> FT_HD float ft_glibc_expf_main(float x, const ft_u64* tab) {
     const double InvLn2N = 0x1.71547652b82fep+5, SHIFT = 0x1.8p+52;                       // N/ln2 (N = 32); 1.5 * 2^52
     const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;   // poly_scaled
-    const uint32_t ux = ft_bits(x), abstop = (ux >> 20) & 0x7ffu;
-    if (abstop >= 0x42bu) {                                                                  // |x| >= 88 or x is NaN
-        if (ux == 0xff800000u) return 0.0f;
-        if (abstop >= 0x7f8u) return x + x;
-        if (x > 0x1.62e42ep6f) return ft_u2f(0x7f800000u);                                   // __math_oflowf: x > log(2^128)
-        if (x < -0x1.9fe368p6f) return 0.0f;                                                 // __math_uflowf: x < log(2^-150)
-        if (x < -0x1.9d1d9ep6f) return ft_u2f(1u);                                           // __math_may_uflowf: 0x1.4p-75f squared = 2^-149
-    }
     const double xd = (double)x;
     // x*N/ln2 = k + r, r in [-1/2, 1/2]; the FMA build fuses the product into both the shifted sum and the remainder
     double kd, r;
@@ -111,6 +104,17 @@ template <bool FMA> FT_HD float ft_glibc_expf(float x, const ft_u64* tab) {
     y = ft_mad<FMA>(z2, r2, y);
     y = y * s;
     return (float)y;
+}
+template <bool FMA> FT_HD float ft_glibc_expf(float x, const ft_u64* tab) {
+    const uint32_t ux = ft_bits(x), abstop = (ux >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                                                                  // |x| >= 88 or x is NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return ft_u2f(0x7f800000u);                                   // __math_oflowf: x > log(2^128)
+        if (x < -0x1.9fe368p6f) return 0.0f;                                                 // __math_uflowf: x < log(2^-150)
+        if (x < -0x1.9d1d9ep6f) return ft_u2f(1u);                                           // __math_may_uflowf: 0x1.4p-75f squared = 2^-149
+    }
+    return ft_glibc_expf_main<FMA>(x, tab);
 }
 
 // ---- logf (e_logf.c) ----------------------------------------------------------------------------------------------------

@@ -348,7 +348,9 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
 // The same run with glibc's expf (FT_OPT_MATH, MATH = 1 kernels): sum += expf(si * (|c_i - p| - r_i)).  FQ: the evaluation passed fast_point_ok and
 // the run the flatten-time bounds, so the clamped five-instruction root equals sqrtf (as in the loop above); the exponential is the full
 // restatement, special cases included, so no range precondition is needed.  Four children per trip: their double-precision chains interleave.
-template <bool FMA, bool FQ>
+// NEAR: every t of the evaluation lies in [-87, 80] (near_point_ok + the flatten-time bounds, as for the fixed exponential's near form): none of expf's
+// special cases can apply and the main path is called directly.
+template <bool FMA, bool FQ, bool NEAR = false>
 __device__ __forceinline__ float smooth_run_spheres_libm(const float* __restrict__ ldsC, uint32_t count, float si, f3 p, float sum, const ft_u64* __restrict__ tab) {
     uint32_t i = 0;
     for (; i + 4u <= count; i += 4u) {
@@ -360,7 +362,8 @@ __device__ __forceinline__ float smooth_run_spheres_libm(const float* __restrict
         for (int j = 0; j < 4; ++j) {
             const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
             const float q = (dx * dx + dy * dy) + dz * dz;
-            e[j] = ft_glibc_expf<FMA>(si * (ft_sq<FQ>(q) - prm[j].w), tab);
+            const float t = si * (ft_sq<FQ>(q) - prm[j].w);
+            e[j] = NEAR ? ft_glibc_expf_main<FMA>(t, tab) : ft_glibc_expf<FMA>(t, tab);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum = sum + e[j];
@@ -368,7 +371,8 @@ __device__ __forceinline__ float smooth_run_spheres_libm(const float* __restrict
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
         const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
-        sum = sum + ft_glibc_expf<FMA>(si * (ft_sq<FQ>((dx * dx + dy * dy) + dz * dz) - prm.w), tab);
+        const float t = si * (ft_sq<FQ>((dx * dx + dy * dy) + dz * dz) - prm.w);
+        sum = sum + (NEAR ? ft_glibc_expf_main<FMA>(t, tab) : ft_glibc_expf<FMA>(t, tab));
     }
     return sum;
 }
@@ -756,7 +760,7 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
     float acc = 0.0f;
     uint32_t leaf = 0;
     const bool fastOk = fast_point_ok(p);
-    const bool nearOk = MATH == 0 && fastOk && near_point_ok(p, S.nearR2);
+    const bool nearOk = fastOk && near_point_ok(p, S.nearR2);
     for (uint32_t pc = 0; pc < S.nInstr; ++pc) {
         const FtInstr FT_CONST* in = as_const(S.instr) + pc;
         const uint32_t op = in->op;
@@ -764,9 +768,11 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
             const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
             if (MATH != 0) {                                           // FT_OPT_MATH: glibc's expf
                 const ft_u64* tab = ft_libm_tab(S);
-                if (S.mathFma) acc = fastOk ? smooth_run_spheres_libm<true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
+                if (S.mathFma) acc = nearOk ? smooth_run_spheres_libm<true, true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
+                                   : fastOk ? smooth_run_spheres_libm<true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
                                             : smooth_run_spheres_libm<true, false>(ldsC + in->data, in->count, in->f0, p, sum0, tab);
-                else acc = fastOk ? smooth_run_spheres_libm<false, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
+                else acc = nearOk ? smooth_run_spheres_libm<false, true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
+                         : fastOk ? smooth_run_spheres_libm<false, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
                                   : smooth_run_spheres_libm<false, false>(ldsC + in->data, in->count, in->f0, p, sum0, tab);
             }
             else if (__builtin_expect(nearOk, 1)) {

@@ -58,8 +58,8 @@ def sphere_loops(dis):
             target = addr + 4 + 4 * off
             body = [i for i in ins if target <= i[0] <= addr]
             # not the hot loops: the latency-mode evaluation (one ray per wave: its loop WRITES the wave's LDS row) and the glibc-mode
-            # loops (double-precision exponentials) also hold four roots, but their placement is not what a frame's time depends on
-            if any(i[2].startswith(("ds_write", "v_fma_f64")) for i in body):
+            # loops (double-precision exponentials: any *_f64 instruction) also hold four roots, but their placement is not what a frame's time depends on
+            if any(i[2].startswith("ds_write") or "_f64" in i[2].split()[0] for i in body):
                 continue
             if sum(1 for i in body if i[2].startswith("v_rsq_f32")) == 4:
                 out.append((sym, "near" if any(i[2].startswith("v_lshl_add_u32") for i in body) else "far", body))
@@ -120,7 +120,7 @@ def text_loops(lines, marks):
             bm = re.match(r"\ts_cbranch_scc\d (\.LBB\d+_\d+)\s*$", lines[i])
             if bm and bm.group(1) in labels:
                 body = [k for k in range(labels[bm.group(1)], i + 1) if lines[k].startswith("\t") and not lines[k].strip().startswith((";", "."))]
-                if any(lines[k].strip().startswith(("ds_write", "v_fma_f64")) for k in body):
+                if any(lines[k].strip().startswith("ds_write") or "_f64" in lines[k].split()[0] for k in body):
                     continue
                 if sum(1 for k in body if lines[k].strip().startswith("v_rsq_f32")) == 4:
                     found = body
