@@ -56,7 +56,34 @@ def tonemap(name):
     return plain, noisy_bmp, np.float32(mx)
 
 
+# FT_OPT_MATH = glibc: the oracle calling the C runtime's expf / logf / powf.  These vectors are what glibc 2.35's FMA build
+# of those functions gives — generated on a host whose libm resolves to it (every x86-64 CPU with FMA and AVX2) — and the GPU's restatement must
+# reproduce them on ANY host, because it does not use the host's libm at all.
+GLIBC_CASES = {"glibc_fma_c3_smooth256_48": (lambda: syn.config3()[0], 48, 48), "glibc_fma_mixed_nested_48x40": (lambda: syn.mixed_nested()[0], 48, 40)}
+
+
+def render_glibc(name):
+    make, W, H = GLIBC_CASES[name]
+    cam = syn.default_camera().as_array()
+    ob.lib.orc_set_libm(1)
+    try:
+        img, cnt = ob.Oracle().scene(make()).render(syn.EPSILON, syn.RAY_LENGTH, W, H, cam, nthreads=4)
+        tm, mx = ob.tone_map(img, gamma=2.2)
+    finally:
+        ob.lib.orc_set_libm(0)
+    counts = np.array([cnt[k] for k in ("rays_primary", "rays_shadow", "hits_primary", "hits_shadow", "flags")], np.int64)
+    return img, counts, np.array([W, H], np.int32), tm, np.float32(mx)
+
+
 if __name__ == "__main__":
+    import fraytracer_amd as _ft
+    if "glibc" in sys.argv[1:]:
+        assert _ft.glibc_build_of_this_host() == 1, "generate the glibc fixtures on a host whose libm resolves to the FMA build"
+        for name in GLIBC_CASES:
+            img, counts, size, tm, mx = render_glibc(name)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, counts=counts, size=size, tonemap=tm, max=mx)
+            print(name, img.shape, counts.tolist())
+        sys.exit(0)
     for name in (sys.argv[1:] or list(CASES) + list(TONEMAP)):
         if name in TONEMAP:
             plain, noisy_bmp, mx = tonemap(name)

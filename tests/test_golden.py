@@ -57,3 +57,36 @@ def test_hip_reproduces_golden_tone_map(gpu, name):
     img = np.load(os.path.join(GOLDEN, make_golden.TONEMAP[name] + ".npz"), allow_pickle=False)["image"]
     assert np.array_equal(ft.Image.toColors(2.2, None, img, gpu), z["plain"])
     assert np.array_equal(ft.Image.toColors(2.2, 19, img, gpu, bmp_order=True), z["noisy_bmp"])
+
+
+def _glibc_235_fma_host():
+    import platform
+    return ft.glibc_build_of_this_host() == 1 and platform.libc_ver() == ("glibc", "2.35")
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.GLIBC_CASES))
+def test_oracle_with_this_hosts_libm_reproduces_the_glibc_golden(name):
+    """the fixtures are glibc 2.35's FMA build: on such a host the oracle calling the real expf / logf / powf gives them again"""
+    if not _glibc_235_fma_host():
+        pytest.skip("the glibc fixtures were generated with glibc 2.35's FMA build of expf / logf / powf")
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    img, counts, _, tm, mx = make_golden.render_glibc(name)
+    assert_bit_equal(img, z["image"], name)
+    assert counts.tolist() == z["counts"].tolist() and np.array_equal(tm, z["tonemap"]) and mx == z["max"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(make_golden.GLIBC_CASES))
+def test_hip_glibc_mode_reproduces_the_glibc_golden(gpu, name):
+    """FT_MATH_GLIBC_FMA on the GPU reproduces glibc 2.35's FMA-build results whatever libm the host has: the restatement runs on the device"""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    W, H = (int(v) for v in z["size"])
+    gpu.set_option("math", 1)
+    try:
+        img, st = gpu.scene(make_golden.GLIBC_CASES[name][0]()).render(syn.EPSILON, syn.RAY_LENGTH, ft.ImageSize(W, H), syn.default_camera())
+        tm = ft.Image.toColors(2.2, None, z["image"], gpu)
+    finally:
+        gpu.set_option("math", 0)
+    assert_bit_equal(img, z["image"], name)
+    assert [st["rays_primary"], st["rays_shadow"], st["hits_primary"], st["hits_shadow"], st["flags"]] == z["counts"].tolist()
+    assert np.array_equal(tm, z["tonemap"])
