@@ -469,7 +469,8 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
         // where no lane can pass :31 was measured at the same time and is slower (+3 %: profiles/r03_walk_variants.txt).  So is a walk that always
         // consumes both candidates of a trip (B's right-hand sides kept across A's evaluation, two evaluation sites): bit-exact, 4 spills at 80
         // registers, +1 % at 4000^2 and +4 % at 1000^2 (same file); and a wave-uniform shortcut for the trips that decide nothing (one ballot
-        // instead of the per-lane decision tree): +3 % at 4000^2, +6 % on C2 (same file).
+        // instead of the per-lane decision tree): +3 % at 4000^2, +6 % on C2 (same file); and loading only the 24 bytes of a record the tests and
+        // the primitive switch need, the material index on evaluation only (to relieve the texture addresser): +6 % at 4000^2 (same file).
         asm volatile("" : "+v"(ra.a), "+v"(ra.b), "+v"(rb.a), "+v"(rb.b));
 #ifdef FT_UNION_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
