@@ -1,7 +1,7 @@
 // console.cpp — the reference's console program (src/FrayTracer.Console/Program.fs:14-100) as a C++ host
 // over libfraytracer_hip: System.Random(19) scene of 1000 tori cut by two spheres, two lights, 1000x1000,
 // epsilon 0.01, ray length 30, timing line, result.bmp.  `--raw file` additionally dumps the float image
-// (tests compare it with the Python host), `--device -1` builds the scene without a GPU and stops.
+// (tests compare it with the Python host), `--device -1` builds the scene without a GPU and stops, `--math glibc` selects FT_OPT_MATH.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -59,16 +59,20 @@ static void saveBitmap(const char* path, ft_ctx* ctx, const std::vector<float>& 
 }
 
 int main(int argc, char** argv) {
-    int size = 1000, tori = 1000, device = 0; const char* raw = nullptr; const char* out = "result.bmp";
+    int size = 1000, tori = 1000, device = 0; const char* raw = nullptr; const char* out = "result.bmp"; bool glibc = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--size") && i + 1 < argc) size = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tori") && i + 1 < argc) tori = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--raw") && i + 1 < argc) raw = argv[++i];
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else if (!strcmp(argv[i], "--math") && i + 1 < argc) glibc = !strcmp(argv[++i], "glibc");
     }
     try {
         Context ctx(device);
+        // --math glibc: MathF.Pow of the tone map (and MathF.Exp / Log of a unionSmooth) as this host's C runtime computes them (FT_OPT_MATH);
+        // glibc picks its FMA build of expf / logf / powf iff the CPU has FMA and AVX2
+        if (glibc) ctx.setOption(FT_OPT_MATH, (__builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2")) ? FT_MATH_GLIBC_FMA : FT_MATH_GLIBC_SSE2);
         DotNetRandom rng(19);                                                              // Program.fs:14
         auto camera = Camera::lookAt({Vector3{0, 0, -10}, Vector3{0, 0, 0}, Vector3{0, 1, 0}, Lens::create(60.0f)});   // :16-22
         auto randomMaterial = [&]() { float r = rng.range_01(), g = rng.range_01(), b = rng.range_01(); return SdfMaterial::createSolid(ctx, FColor::ofRGB(r, g, b)); };
