@@ -59,6 +59,7 @@ struct ft_ctx {
     int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
     int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
     int optChunk = 64;                                     // FT_OPT_CHUNK: jobs per grab (experiments: 64 = one 8x8 tile, 32, 16)
+    int optCull = 1;                                       // FT_OPT_CULL: exact child culling in the lean kernel (kernels.hip); 0 = every child, every round
     int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
 
@@ -201,7 +202,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 // tables behind that, 8-byte aligned (kernels.hip ft_libm_lds_offset)
 // (kernels.hip ft_libm_lds_offset); the lean kernel keeps one row of FT_COOP_SEG floats per wave behind everything (16-byte aligned) for
 // the latency mode (kernels.hip ft_coop_lds_offset)
-#define FT_COOP_SEG_FLOATS 256
+#define FT_COOP_SEG_FLOATS 1024               // = FT_CULL_ROW (kernels.hip): 256 float4 records of culled children; its first 256 floats serve the latency mode
 // traceLaunch: the lean trace kernel keeps its accumulator in a register and is launched with nSlots = 0 (launchTrace) — 2 KB per workgroup
 // that decide between 6 and 7 resident workgroups per CU; every other user of a lean scene (ft_eval_distance) runs the general interpreter
 size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false) {
@@ -277,6 +278,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.S = s->dev;
     if (s->dev.fastPath == 1u) a.S.nSlots = 0;             // the lean kernel uses no value slots: its LDS layout has none (ldsBytes)
     a.math = libm ? 1u : 0u;
+    a.cull = (s->dev.fastPath == 1u && c->optCull) ? 1u : 0u;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
     a.materialsExt = s->dMaterialsExt;
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
@@ -327,6 +329,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
     case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
     case FT_OPT_CHUNK: if (value != 64 && value != 32 && value != 16) return setErr(FT_ERR_INVALID, "FT_OPT_CHUNK: 64, 32 or 16"); c->optChunk = value; return FT_OK;
+    case FT_OPT_CULL: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CULL: 0 or 1"); c->optCull = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_MATH:
         if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
@@ -344,6 +347,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_MATH: *value = c->optMath; return FT_OK;
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
+    case FT_OPT_CULL: *value = c->optCull; return FT_OK;
     case FT_OPT_CHUNK: *value = c->optChunk; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
@@ -595,7 +599,7 @@ int ft_collect_stats(ft_ctx* c, ft_stats* st) {
         st->flags = h.flags; st->kernel_ms = (float)ms; st->wave_evals = h.wave_evals;
         st->shader_mhz = h.clk_ref ? (float)((double)h.clk_shader / (double)h.clk_ref * 100.0) : 0.0f;   // s_memrealtime: 100 MHz
         st->tail_fraction = h.sdf_evals ? (float)((double)h.coop_evals / (double)h.sdf_evals) : 0.0f;
-        st->reserved = 0.0f;
+        st->culled_fraction = h.cull_total ? (float)((double)h.cull_skipped / (double)h.cull_total) : 0.0f;
     }
     return FT_OK;
 }

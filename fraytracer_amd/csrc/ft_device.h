@@ -106,6 +106,7 @@ struct FtSceneDev {             // passed by value as kernel argument
 struct FtStatsDev {
     unsigned long long rays_primary, rays_shadow, rays_ext, hits_primary, hits_shadow, sdf_evals, flags, wave_evals;
     unsigned long long coop_evals;            // evaluations done in latency mode (one ray per wave)
+    unsigned long long cull_total, cull_skipped;   // lean kernel: (child, ray) pairs the culling pass looked at / dropped, in units of 64
     unsigned long long clk_shader, clk_ref;   // s_memtime / s_memrealtime ticks the first wave of block 0 lived (summed over launches):
                                               // their ratio x the constant s_memrealtime rate (100 MHz) = the shader clock the kernel ran at
 };

@@ -29,7 +29,8 @@ struct FtRenderArgs {
     float* out;
     uint32_t* counter;        // global job cursor (zeroed before every launch)
     FtStatsDev* stats;
-    uint32_t nJobs, chunk, tilesY, pad1;
+    uint32_t nJobs, chunk, tilesY;
+    uint32_t cull;            // lean kernel: 1 = drop, per wave and round, the children whose terms are exact no-ops (kernels.hip "Exact child culling")
     // EXTENSIONS (spp = 1, aoSamples = 0 is the reference): sample plane s of the frame is written at
     // out + s * planeFloats and resolved by ft_resolve_kernel; ambient-occlusion rays per primary hit
     uint32_t spp, sppN, aoSamples, jobsPerPlane;

@@ -752,12 +752,122 @@ __device__ __forceinline__ void ft_eval_coop(const FtSceneDev& S, const f3 p, fl
     outLeaf = sl[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact child culling for the lean kernel (round 3; FT_OPT_CULL).
+//
+// unionSmooth adds its children's terms exp(si * d_i) one after the other in float32 (SdfForm.fs:77-80).  A term below half an ulp of
+// the running sum leaves that sum unchanged — bit for bit, under round-to-nearest — so the child need not be evaluated at all.  The
+// rays of a wave are neighbours (burst refill: one 8x8 tile at a time), so whether a child is such a no-op can be decided ONCE PER WAVE
+// AND ROUND from bounds that hold for all of its rays; in the C3 frame a third of all (child, evaluation) pairs go that way.
+//
+// Once per round, all 64 lanes (also those without a ray) take part: q0 = the query point of the first lane that has one, rho >= the
+// distance of every such point from q0.  Lane k of pass j looks at child i = 64 j + k (centre c, radius r) and computes, in plain f32
+// with generous slack,  dlo <= |c - p| - r <= dhi  for every ray's p (triangle inequality: | |c - q0| - r +- rho |), hence
+//     low_i  <=  the child's term in every lane          (2^(si dhi log2e - 0.02) by v_exp_f32)
+//     n_i    >=  the exponent n of the term in every lane (every exponential here returns less than 2^(n+1), n = round(t log2 e), t <= si dlo)
+// and an exclusive prefix sum over the children in list order gives  Slow_i  <=  the running sum every lane holds in front of child i:
+// the sum of the lower bounds of ALL earlier children, times (1 - 2^-8), which covers the rounding of that prefix sum, of the lanes'
+// own sequential sums (256 x 2^-24) and of their exponentials (< 1 ulp), and the culled children among them, whose lower bounds are
+// counted although their terms were absorbed (they add up to less than 255 x 2^-24 of the sum).  Child i is dropped for this wave and
+// round iff Slow_i is a normal number and  n_i + 1 <= exponent(Slow_i) - 24,  i.e.  term < 2^(n_i + 1) <= half an ulp of any float
+// >= Slow_i — by induction over the list the running sums are then exactly the reference's.  The first child is never dropped
+// (Slow_0 = 0); NaN, infinite or huge points switch the pass off.  Survivors keep their order: their parameter records are copied,
+// compacted, into the wave's own LDS row, which the unchanged sphere loops then read instead of the staged constants.
+// Cost: ~250 wave-instructions per round against 26 per child and ray saved.
+// ------------------------------------------------------------------------------------------------
+#define FT_CULL_MAX 256                        // children per culling pass (the wave's LDS row: FT_CULL_MAX float4); a longer run's tail is evaluated in full
+#define FT_CULL_ROW (4 * FT_CULL_MAX)          // floats; the row's first FT_COOP_SEG floats double as the latency mode's row (never used in the same round)
+#define FT_CULL_MIN 32u                        // runs shorter than this are not worth the pass
+#define FT_CULL_NONE 0xffffffffu
+__device__ __forceinline__ f3 ft_readlane3(f3 v, int l) {
+    return mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), l)),
+               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), l)));
+}
+__device__ __forceinline__ float ft_wave_max_all(float v) {            // all 64 lanes execute; every lane gets the maximum
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// -> survivors among the first min(count, FT_CULL_MAX) children of instruction 0, their records in row[0 ..), or FT_CULL_NONE (row untouched).
+// active / am: lanes that evaluate p this round (am = __ballot(active) != 0).  Wave-uniform result; executed by all 64 lanes.
+__device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const f3 p, bool active, unsigned long long am,
+                                                     const float* __restrict__ ldsC, float* __restrict__ row) {
+    const FtInstr FT_CONST* in = as_const(S.instr);
+    const uint32_t flags = in->flags, count = in->count;
+    const float si = in->f0;
+    if (in->op != FT_OP_SMOOTH_RUN || (flags & (FT_FLAG_INIT | FT_FLAG_FAST)) != (FT_FLAG_INIT | FT_FLAG_FAST) || count < FT_CULL_MIN || !(si < 0.0f)) return FT_CULL_NONE;
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p.x), __builtin_fabsf(p.y)), __builtin_fabsf(p.z));
+    const bool bad = !(m < FT_FAST_P_MAX) || p.x != p.x || p.y != p.y || p.z != p.z;
+    if (__ballot(active && bad) != 0ull) return FT_CULL_NONE;         // such evaluations take the exact loop anyway
+    const uint32_t lane = threadIdx.x & 63u;
+    const f3 q0 = ft_readlane3(p, __ffsll((long long)am) - 1);
+    const float ex = p.x - q0.x, ey = p.y - q0.y, ez = p.z - q0.z;
+    const float rho2 = ft_wave_max_all(active ? (ex * ex + ey * ey) + ez * ez : 0.0f);
+    const float rho = __builtin_amdgcn_sqrtf(rho2) * 1.001f + 1e-6f;   // >= |p - q0| of every active lane (v_sqrt_f32: 1 ulp)
+    const uint32_t n = count < FT_CULL_MAX ? count : FT_CULL_MAX;
+    const float4* src = reinterpret_cast<const float4*>(ldsC + in->data);
+    float4* dst = reinterpret_cast<float4*>(row);
+    float carry = 0.0f;                                                // sum of the lower bounds of the passes done (wave-uniform)
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool have = i < n;
+        const float4 prm = src[have ? i : n - 1u];
+        const float dx = prm.x - q0.x, dy = prm.y - q0.y, dz = prm.z - q0.z;
+        const float dc = __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) - prm.w;      // |c - q0| - r, within a few ulp of 20000
+        const float slack = 0.01f + rho;                               // 0.01 >> every rounding here and in the lanes' own distances
+        const float dlo = dc - slack, dhi = dc + slack;
+        const float low = have ? __builtin_amdgcn_exp2f(__builtin_fmaxf(si * dhi * 1.44269504f - 0.02f, -200.0f)) : 0.0f;
+        float incl = low;                                              // inclusive prefix sum over the lanes = over the children in list order
+        for (int off = 1; off < 64; off <<= 1) { const float v = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += v; }
+        float excl = __shfl_up(incl, 1, 64); if (lane == 0u) excl = 0.0f;
+        const float slow = (carry + excl) * 0.99609375f;              // 1 - 2^-8
+        const uint32_t sbits = __float_as_uint(slow);
+        const float x = __builtin_fminf(__builtin_fmaxf(si * dlo * 1.44269504f, -1000.0f), 1000.0f);
+        const int nUp = (int)__builtin_floorf(x + 0.52f) + 1;
+        const bool drop = have && x == x && sbits >= 0x00800000u && sbits < 0x7f800000u && nUp + 1 <= (int)(sbits >> 23) - 127 - 24;
+        const bool keep = have && !drop;
+        const unsigned long long km = __ballot(keep);
+        if (keep) dst[kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = prm;
+        kept += (uint32_t)__popcll(km);
+        carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+    }
+    return kept;
+}
+
 // Lean evaluator for scenes whose whole program is {fast sphere SMOOTH_RUN..., SMOOTH_FIN, SETLEAF}
 // (FtSceneDev.fastPath == 1, decided when the scene is flattened): the accumulator lives in a VGPR,
 // no value slots, no primitive switch — the kernel variant built on it needs far fewer registers.
+// one run of sphere children in the regime the evaluation allows (wave-uniform fastOk / nearOk): sum0 + the run's terms, in list order
+template <int MATH>
+__device__ __forceinline__ float ft_run_spheres(const FtSceneDev& S, const float* __restrict__ c, uint32_t count, float si, const f3 p, float sum0,
+                                                bool fastOk, bool nearOk) {
+    if (MATH != 0) {                                                   // FT_OPT_MATH: glibc's expf
+        const ft_u64* tab = ft_libm_tab(S);
+        if (S.mathFma) return nearOk ? smooth_run_spheres_libm<true, true, true>(c, count, si, p, sum0, tab)
+                            : fastOk ? smooth_run_spheres_libm<true, true>(c, count, si, p, sum0, tab)
+                                     : smooth_run_spheres_libm<true, false>(c, count, si, p, sum0, tab);
+        return nearOk ? smooth_run_spheres_libm<false, true, true>(c, count, si, p, sum0, tab)
+             : fastOk ? smooth_run_spheres_libm<false, true>(c, count, si, p, sum0, tab)
+                      : smooth_run_spheres_libm<false, false>(c, count, si, p, sum0, tab);
+    }
+    if (__builtin_expect(nearOk, 1)) {
+#ifndef FT_SQRT_5
+        const int pw = ft_strength_pw(si);                             // wave-uniform: the strength is an instruction field
+        if (pw == 2) return smooth_run_spheres_fast<true, 2>(c, count, si, p, sum0);
+        if (pw == 1) return smooth_run_spheres_fast<true, 1>(c, count, si, p, sum0);
+        if (pw == 3) return smooth_run_spheres_fast<true, 3>(c, count, si, p, sum0);
+#endif
+        return smooth_run_spheres_fast<true>(c, count, si, p, sum0);
+    }
+    if (fastOk) return smooth_run_spheres_fast<false>(c, count, si, p, sum0);
+    float acc = sum0;                                                  // exact loop (SdfForm.fs:77-80, :129)
+    for (uint32_t i = 0; i < count; ++i) acc = acc + ft_exp(si * (ft_distance(mk3(c[4u * i], c[4u * i + 1u], c[4u * i + 2u]), p) - c[4u * i + 3u]));
+    return acc;
+}
+
 template <int MATH>
 __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, const f3 p, const float* __restrict__ ldsC,
-                                                       float& outD, uint32_t& outLeaf) {
+                                                       float& outD, uint32_t& outLeaf, const float* __restrict__ cullRow = nullptr, uint32_t cullN = FT_CULL_NONE) {
     float acc = 0.0f;
     uint32_t leaf = 0;
     const bool fastOk = fast_point_ok(p);
@@ -766,33 +876,18 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
         const FtInstr FT_CONST* in = as_const(S.instr) + pc;
         const uint32_t op = in->op;
         if (op == FT_OP_SMOOTH_RUN) {
-            const float sum0 = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
-            if (MATH != 0) {                                           // FT_OPT_MATH: glibc's expf
-                const ft_u64* tab = ft_libm_tab(S);
-                if (S.mathFma) acc = nearOk ? smooth_run_spheres_libm<true, true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
-                                   : fastOk ? smooth_run_spheres_libm<true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
-                                            : smooth_run_spheres_libm<true, false>(ldsC + in->data, in->count, in->f0, p, sum0, tab);
-                else acc = nearOk ? smooth_run_spheres_libm<false, true, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
-                         : fastOk ? smooth_run_spheres_libm<false, true>(ldsC + in->data, in->count, in->f0, p, sum0, tab)
-                                  : smooth_run_spheres_libm<false, false>(ldsC + in->data, in->count, in->f0, p, sum0, tab);
-            }
-            else if (__builtin_expect(nearOk, 1)) {
-#ifndef FT_SQRT_5
-                const int pw = ft_strength_pw(in->f0);                 // wave-uniform: the strength is an instruction field
-                if (pw == 2) acc = smooth_run_spheres_fast<true, 2>(ldsC + in->data, in->count, in->f0, p, sum0);
-                else if (pw == 1) acc = smooth_run_spheres_fast<true, 1>(ldsC + in->data, in->count, in->f0, p, sum0);
-                else if (pw == 3) acc = smooth_run_spheres_fast<true, 3>(ldsC + in->data, in->count, in->f0, p, sum0);
-                else
-#endif
-                acc = smooth_run_spheres_fast<true>(ldsC + in->data, in->count, in->f0, p, sum0);
-            }
-            else if (fastOk) acc = smooth_run_spheres_fast<false>(ldsC + in->data, in->count, in->f0, p, sum0);
-            else {                                                     // exact loop (SdfForm.fs:77-80, :129)
-                acc = sum0;
-                for (uint32_t i = 0; i < in->count; ++i) {
-                    const float* c = ldsC + in->data + 4u * i;
-                    acc = acc + ft_exp(in->f0 * (ft_distance(mk3(c[0], c[1], c[2]), p) - c[3]));
-                }
+            acc = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
+            // the run, or — where ft_cull_children ran for this wave and round — the survivors of its first FT_CULL_MAX children (in the wave's
+            // LDS row) and then the rest of the run in full; one inlined copy of the loops serves both pieces
+            const bool culled = pc == 0u && cullN != FT_CULL_NONE && fastOk;
+            const float* c = culled ? cullRow : ldsC + in->data;
+            uint32_t n = culled ? cullN : in->count;
+            uint32_t rest = culled && in->count > FT_CULL_MAX ? in->count - FT_CULL_MAX : 0u;
+#pragma nounroll
+            for (;;) {
+                acc = ft_run_spheres<MATH>(S, c, n, in->f0, p, acc, fastOk, nearOk);
+                if (rest == 0u) break;
+                c = ldsC + in->data + 4u * FT_CULL_MAX; n = rest; rest = 0u;
             }
         }
         else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log_m<MATH>(acc, S) * in->f0;
@@ -815,14 +910,10 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
 // bit-identical by construction; it is also cheaper in wave instructions as soon as fewer than ~15 lanes hold a ray, so the mode is used
 // whenever a wave is that empty, not only at the end of a launch.
 // ------------------------------------------------------------------------------------------------
-#define FT_COOP_SEG 256                       // children per segment = floats of LDS per wave
+#define FT_COOP_SEG 256                       // children per segment = floats of the wave's LDS row the mode uses
 __device__ __forceinline__ uint32_t ft_coop_lds_offset(const FtSceneDev& S, bool libm) {
     const uint32_t end = libm ? ft_libm_lds_offset(S) + 2u * FT_LIBM_TAB_DOUBLES : FT_LDS_HDR_FLOATS + 2u * S.nSlots * FT_BLOCK + S.nStage;
     return (end + 3u) & ~3u;                  // 16-byte aligned: the row is written and read as float4
-}
-__device__ __forceinline__ f3 ft_readlane3(f3 v, int l) {
-    return mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), l)),
-               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), l)));
 }
 // one child's term exp(si * (|c - p| - r)) in the regime the point allows: 2 = near (exponent-add exp), 1 = far (ldexp exp), 0 = exact
 // forms — all three give the same bits wherever two of them are valid (ft_selftest_fastmath), so the choice is only about cost
@@ -1150,7 +1241,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
 #endif
     __syncthreads();
 
-    float* coopRow = ft_lds + ft_coop_lds_offset(a.S, MATH != 0) + (tid >> 6) * FT_COOP_SEG;   // lean kernel: this wave's row of the latency mode
+    float* coopRow = ft_lds + ft_coop_lds_offset(a.S, MATH != 0) + (tid >> 6) * FT_CULL_ROW;   // lean kernel: this wave's row (latency mode / culled children)
+    uint32_t cullSkipped = 0, cullTotal = 0;                           // (child, ray) pairs the culling pass dropped / looked at (wave-uniform sums)
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
     uint32_t waveEvals = 0;                                            // evaluation rounds of this wave (lane-utilisation statistic)
     uint32_t coopEvals = 0;                                            // evaluations done in latency mode (wave-uniform)
@@ -1241,13 +1333,22 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 }
             }
         }
+        // ---- lean kernel: drop the children whose terms no ray of this wave can feel this round ("Exact child culling") ----
+        uint32_t cullN = FT_CULL_NONE;
+        if (VARIANT == 1 && a.cull != 0u && !coop && am != 0ull) {
+            cullN = ft_cull_children(a.S, query_point(), active, am, ldsC, coopRow);
+            if (cullN != FT_CULL_NONE) {
+                const uint32_t looked = as_const(a.S.instr)->count < FT_CULL_MAX ? as_const(a.S.instr)->count : FT_CULL_MAX;
+                cullTotal += looked * (uint32_t)__popcll(am) >> 6; cullSkipped += (looked - cullN) * (uint32_t)__popcll(am) >> 6;   // in units of 64 pairs
+            }
+        }
         if (active) {
             float d; uint32_t leaf;
             FT_UDBG_T0(tEval);
             if (coop) { d = dCoop; leaf = leafCoop; }
             else {
                 const f3 q = query_point();
-                if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf);
+                if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf, coopRow, cullN);
                 else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
             }
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
@@ -1323,6 +1424,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         if (ex) atomicAdd(&a.stats->rays_ext, ex);
         atomicAdd(&a.stats->wave_evals, (unsigned long long)waveEvals);
         if (coopEvals) atomicAdd(&a.stats->coop_evals, (unsigned long long)coopEvals);
+        if (cullTotal) { atomicAdd(&a.stats->cull_total, (unsigned long long)cullTotal); atomicAdd(&a.stats->cull_skipped, (unsigned long long)cullSkipped); }
         if (fl | fc) atomicOr(&a.stats->flags, fl | fc);
         if (blockIdx.x == 0 && tid == 0) { atomicAdd(&a.stats->clk_shader, clock64() - clk0[0]); atomicAdd(&a.stats->clk_ref, wall_clock64() - clk0[1]); }
     }

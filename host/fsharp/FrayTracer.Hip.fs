@@ -26,7 +26,7 @@ type FtRenderParams =
 [<Struct; StructLayout(LayoutKind.Sequential)>]
 type FtStats =
     { RaysPrimary : uint64; RaysShadow : uint64; RaysExt : uint64; HitsPrimary : uint64; HitsShadow : uint64
-      SdfEvals : uint64; Flags : uint64; KernelMs : float32; Reserved : float32; WaveEvals : uint64
+      SdfEvals : uint64; Flags : uint64; KernelMs : float32; CulledFraction : float32; WaveEvals : uint64
       ShaderMHz : float32; TailFraction : float32 }
 
 /// ft_camera (48 B).  The reference's `Camera` (Camera.fs:16-22) is an ordinary F# record — a reference type with

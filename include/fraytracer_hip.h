@@ -87,7 +87,7 @@ typedef struct ft_stats {         /* filled per call; all counts are exact */
     uint64_t sdf_evals;           /* scene-SDF evaluations (march steps + normal probes) */
     uint64_t flags;               /* bit0 NaN distance met, bit2 step cap hit (reference would not terminate) */
     float kernel_ms;              /* HIP-event time of the render kernel(s) of this call */
-    float reserved;
+    float culled_fraction;        /* lean kernel: share of the (child, ray) pairs of the smooth union that were dropped as exact no-ops (FT_OPT_CULL) */
     uint64_t wave_evals;          /* wave-level evaluation rounds: sdf_evals / (64 * wave_evals) = lane utilisation */
     float shader_mhz;             /* shader clock the render kernel(s) of this call ran at: s_memtime ticks / s_memrealtime ticks
                                    * (constant 100 MHz) of one wave that lives as long as the kernel; 0 if unknown */
@@ -117,6 +117,8 @@ typedef enum ft_option {
                                    * -1 (default) = the kernel's own threshold, 0 = off, 1..64 */
     FT_OPT_MATH = 6,              /* ft_math_mode (below); default FT_MATH_FIXED */
     FT_OPT_CHUNK = 8,             /* 64 (default): rays a wave takes per grab = one 8x8 tile; 32 / 16: half / quarter tiles (experiments) */
+    FT_OPT_CULL = 9,              /* 1 (default): the smooth-union kernel drops, per wave and round, the children whose terms are below half an ulp
+                                   * of the running sum in every ray of the wave (exact: the sum is unchanged bit for bit); 0: every child, every round */
     FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's

@@ -106,7 +106,7 @@ int main(void) {
     O(ft_render_params, x0); O(ft_render_params, stripe_width); O(ft_render_params, spp); O(ft_render_params, epsilon);
     O(ft_render_params, length); O(ft_render_params, ao_samples); O(ft_render_params, ao_radius); O(ft_render_params, max_bounces);
     O(ft_render_params, spectral);
-    O(ft_stats, hits_primary); O(ft_stats, sdf_evals); O(ft_stats, flags); O(ft_stats, kernel_ms); O(ft_stats, reserved); O(ft_stats, wave_evals); O(ft_stats, shader_mhz);
+    O(ft_stats, hits_primary); O(ft_stats, sdf_evals); O(ft_stats, flags); O(ft_stats, kernel_ms); O(ft_stats, culled_fraction); O(ft_stats, wave_evals); O(ft_stats, shader_mhz);
     O(ft_tonemap_params, gamma); O(ft_tonemap_params, dither); O(ft_tonemap_params, seed); O(ft_tonemap_params, bmp_order);
     return 0;
 }
@@ -142,7 +142,7 @@ def test_header_is_plain_c99_with_the_reference_layouts(tmp_path):
                     "ft_render_params.epsilon": 32, "ft_render_params.length": 36, "ft_render_params.ao_samples": 40,
                     "ft_render_params.ao_radius": 44, "ft_render_params.max_bounces": 48, "ft_render_params.spectral": 52,
                     "ft_stats.hits_primary": 24, "ft_stats.sdf_evals": 40, "ft_stats.flags": 48, "ft_stats.kernel_ms": 56,
-                    "ft_stats.reserved": 60, "ft_stats.wave_evals": 64, "ft_stats.shader_mhz": 72,
+                    "ft_stats.culled_fraction": 60, "ft_stats.wave_evals": 64, "ft_stats.shader_mhz": 72,
                     "ft_tonemap_params.gamma": 0, "ft_tonemap_params.dither": 4, "ft_tonemap_params.seed": 8,
                     "ft_tonemap_params.bmp_order": 12}
     for k, v in want_offsets.items():

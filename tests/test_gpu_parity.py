@@ -327,6 +327,42 @@ def test_hand_out_options_do_not_change_the_frame(gpu, oracle):
         gpu.set_option("chunk", 64); gpu.set_option("guided", 0); gpu.set_option("tail_k", -1)
 
 
+def test_child_culling_is_exact_and_happens(gpu, oracle):
+    """FT_OPT_CULL (lean kernel): per wave and round, children whose terms are below half an ulp of the running sum in every ray of the
+    wave are not evaluated.  The frame and the counters are the oracle's with the pass on and off; with it on a sizeable share of the
+    (child, ray) pairs is dropped, with it off none — for several strengths, child counts beyond one culling row, a second (non-culled)
+    run's worth of children, both arithmetics, and with the latency mode forced on (which bypasses the pass)."""
+    cam = syn.default_camera()
+    try:
+        # the pass needs the rays of a wave (one 8x8 tile) close together, i.e. a fine pixel pitch = 1 / max(W, H): wide, low frames
+        for n, W, H, strength in ((256, 3072, 24, 0.25), (300, 2048, 16, 0.5), (64, 1024, 24, 0.1), (40, 64, 56, 1.0), (256, 96, 88, 0.3)):
+            scene, _ = syn.config3(n=n, size=W, strength=strength)
+            ds, os_ = both(gpu, oracle, scene)
+            want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array())
+            for cull in (1, 0):
+                gpu.set_option("cull", cull)
+                g, gst = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+                assert_bit_equal(g, want, f"{n} spheres, strength {strength}, cull {cull}")
+                check_counts(gst, ocnt)
+                if cull == 0: assert gst["culled_fraction"] == 0.0
+                elif W >= 1024 and strength <= 0.25: assert gst["culled_fraction"] > 0.05, gst   # (a softer union decays too slowly to drop anything in a ball of radius 4)
+        gpu.set_option("cull", 1); gpu.set_option("tail_k", 64)
+        scene, _ = syn.config3(n=256, size=2048)
+        ds, os_ = both(gpu, oracle, scene)
+        g, gst = ds.render(EPS, LEN, ft.ImageSize(2048, 16), cam)
+        assert_bit_equal(g, os_.render(EPS, LEN, 2048, 16, cam.as_array())[0], "latency mode forced: no culling pass")
+        assert gst["culled_fraction"] == 0.0
+        gpu.set_option("tail_k", -1); gpu.set_option("math", ft.glibc_build_of_this_host()); oracle.lib.orc_set_libm(1)
+        try:
+            g, gst = ds.render(EPS, LEN, ft.ImageSize(2048, 16), cam)
+            assert_bit_equal(g, os_.render(EPS, LEN, 2048, 16, cam.as_array())[0], "culling in glibc mode")
+            assert gst["culled_fraction"] > 0.05, gst
+        finally:
+            gpu.set_option("math", 0); oracle.lib.orc_set_libm(0)
+    finally:
+        gpu.set_option("cull", 1); gpu.set_option("tail_k", -1)
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
