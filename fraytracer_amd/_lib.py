@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FRAYTRACER_HIP_LIB: diagnostic builds only (tools/union_divergence.py); the product is the in-tree library
 LIB_PATH = os.environ.get("FRAYTRACER_HIP_LIB") or os.path.join(_HERE, "libfraytracer_hip.so")
 
-FT_OPT_REFILL_MIN, FT_OPT_MAX_BLOCKS_PER_CU, FT_OPT_HOST_CHUNKS, FT_OPT_HOST_PIN, FT_OPT_TAIL_K, FT_OPT_MATH, FT_OPT_GUIDED, FT_OPT_CHUNK, FT_OPT_CULL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+FT_OPT_REFILL_MIN, FT_OPT_MAX_BLOCKS_PER_CU, FT_OPT_HOST_CHUNKS, FT_OPT_HOST_PIN, FT_OPT_TAIL_K, FT_OPT_MATH, FT_OPT_GUIDED, FT_OPT_CHUNK, FT_OPT_CULL, FT_OPT_ESCAPE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 FT_MATH_FIXED, FT_MATH_GLIBC_FMA, FT_MATH_GLIBC_SSE2 = 0, 1, 2
 FT_OK, FT_ERR_INVALID, FT_ERR_NO_DEVICE, FT_ERR_HIP, FT_ERR_UNSUPPORTED, FT_ERR_EMPTY, FT_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 
@@ -140,6 +140,7 @@ SYMBOLS = {
     "ft_scene_info_get": (C.c_int, [_P, C.POINTER(SceneInfo)]),
     "ft_scene_grid_shape": (C.c_int, [_P, C.c_int32, _F3, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ft_scene_grid_dump": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    "ft_scene_support_sphere": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "ft_math_eval": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
     "ft_selftest_fastmath": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ft_selftest_libm": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64)]),

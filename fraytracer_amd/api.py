@@ -369,7 +369,7 @@ class Device:
 
     OPTIONS = {"refill_min": _lib.FT_OPT_REFILL_MIN, "max_blocks_per_cu": _lib.FT_OPT_MAX_BLOCKS_PER_CU,
                "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN, "math": _lib.FT_OPT_MATH,
-               "tail_k": _lib.FT_OPT_TAIL_K, "guided": _lib.FT_OPT_GUIDED, "chunk": _lib.FT_OPT_CHUNK, "cull": _lib.FT_OPT_CULL}
+               "tail_k": _lib.FT_OPT_TAIL_K, "guided": _lib.FT_OPT_GUIDED, "chunk": _lib.FT_OPT_CHUNK, "cull": _lib.FT_OPT_CULL, "escape": _lib.FT_OPT_ESCAPE}
 
     def set_option(self, name, value):
         """ft_ctx_set_option: per-context switches (the library reads no environment variables)"""
@@ -465,6 +465,12 @@ class DeviceScene:
         i = _lib.SceneInfo()
         check(lib.ft_scene_info_get(self._scene, C.byref(i)))
         return {k: getattr(i, k) for k, _ in i._fields_}
+
+    def support_sphere(self):
+        """(cx, cy, cz, radius) of the sphere outside of which (grown by epsilon) no evaluation can be a hit; radius < 0: none known"""
+        cr = (C.c_float * 4)()
+        check(lib.ft_scene_support_sphere(self._scene, cr))
+        return tuple(float(v) for v in cr)
 
     def grid(self, g=0):
         info = (C.c_float * 6)()

@@ -59,6 +59,7 @@ struct ft_ctx {
     int optMath = FT_MATH_FIXED;                           // FT_OPT_MATH: arithmetic of MathF.Exp / Log / Pow
     int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
     int optChunk = 64;                                     // FT_OPT_CHUNK: jobs per grab (experiments: 64 = one 8x8 tile, 32, 16)
+    int optEscape = 1;                                     // FT_OPT_ESCAPE: rays that can no longer reach the scene's support sphere end as misses at once (kernels.hip ft_never_enters)
     int optCull = 1;                                       // FT_OPT_CULL: exact child culling in the lean kernel (kernels.hip); 0 = every child, every round
     int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
@@ -180,6 +181,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d.nInstr = f.nMainInstr; d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
     d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ; d.nGlass = f.nGlass;
+    d.escC[0] = f.escC[0]; d.escC[1] = f.escC[1]; d.escC[2] = f.escC[2]; d.escR = f.escR;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));
@@ -279,6 +281,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     if (s->dev.fastPath == 1u) a.S.nSlots = 0;             // the lean kernel uses no value slots: its LDS layout has none (ldsBytes)
     a.math = libm ? 1u : 0u;
     a.cull = (s->dev.fastPath == 1u && c->optCull) ? 1u : 0u;
+    if (!c->optEscape) a.S.escR = -1.0f;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
     a.materialsExt = s->dMaterialsExt;
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
@@ -329,6 +332,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_HOST_PIN: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_HOST_PIN: 0 or 1"); c->optHostPin = value; return FT_OK;
     case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
     case FT_OPT_CHUNK: if (value != 64 && value != 32 && value != 16) return setErr(FT_ERR_INVALID, "FT_OPT_CHUNK: 64, 32 or 16"); c->optChunk = value; return FT_OK;
+    case FT_OPT_ESCAPE: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_ESCAPE: 0 or 1"); c->optEscape = value; return FT_OK;
     case FT_OPT_CULL: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CULL: 0 or 1"); c->optCull = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_MATH:
@@ -348,6 +352,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
     case FT_OPT_CULL: *value = c->optCull; return FT_OK;
+    case FT_OPT_ESCAPE: *value = c->optEscape; return FT_OK;
     case FT_OPT_CHUNK: *value = c->optChunk; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");
     }
@@ -927,6 +932,12 @@ int ft_scene_grid_shape(const ft_scene* s, int32_t g, float info[6], int32_t cou
     const int32_t nc = G.count[0] * G.count[1] * G.count[2];
     if (nCells) *nCells = nc;
     if (nItems) *nItems = (int32_t)(s->flat.cellStart[G.cellBase + nc] - s->flat.cellStart[G.cellBase]);
+    return FT_OK;
+}
+
+int ft_scene_support_sphere(const ft_scene* s, float cr[4]) {
+    if (!s || !cr) return setErr(FT_ERR_INVALID, "null argument");
+    cr[0] = s->flat.escC[0]; cr[1] = s->flat.escC[1]; cr[2] = s->flat.escC[2]; cr[3] = s->flat.escR;
     return FT_OK;
 }
 

@@ -99,6 +99,8 @@ struct FtSceneDev {             // passed by value as kernel argument
     float nearR2;               // |p|^2 <= nearR2  =>  every t of the fast sphere runs is >= -87 (exp result normal)
     uint32_t fastQ;             // 1: every union candidate admits the clamped fast sqrt (scene.cpp: unionFastQ)
     uint32_t nGlass;            // EXTENSION: glass materials in the scene
+    float escC[3], escR;        // support sphere of the scene's form (scene.cpp supportOf): no evaluation outside of it, grown by epsilon, can be a hit;
+                                // escR < 0: none known, or FT_OPT_ESCAPE = 0
     uint32_t mathFma;           // FT_OPT_MATH (set per launch, not by the flattener): 1 = glibc's FMA build of expf / logf, 0 = its SSE2 build
                                 // (read by the *_libm kernels only)
 };

@@ -1053,6 +1053,22 @@ __device__ __forceinline__ void write_ray(float* o, f3 origin, f3 dir, float len
     o[0] = origin.x; o[1] = origin.y; o[2] = origin.z; o[3] = dir.x; o[4] = dir.y; o[5] = dir.z; o[6] = len; o[7] = eps;
 }
 
+// Can the ray o + t dir, t >= 0, still come within eps of the scene's support sphere (FtSceneDev.escC / escR, scene.cpp supportOf)?  If not,
+// no evaluation along it can be below eps (SdfForm.fs:98), so its march ends in a miss whatever the steps are: the lane takes that exit at
+// once (FT_OPT_ESCAPE).  Outside and heading away (the distance to the centre only grows), or outside and passing by (closest approach
+// |w|^2 - b^2 / |dir|^2 beyond the radius); 4e-6 |w|^2 covers the rounding of the three dot products.  Any NaN: "may still come".
+__device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o, const f3 dir, float eps) {
+    if (!(S.escR >= 0.0f)) return false;
+    const f3 w = o - mk3(S.escC[0], S.escC[1], S.escC[2]);
+    const float re = S.escR + eps;
+    const float ww = ft_dot(w, w), cc = ww - re * re, tol = 4e-6f * ww;
+    if (!(cc > tol)) return false;                                     // inside, or too close to tell
+    const float b = ft_dot(w, dir);
+    if (b >= 0.0f) return true;
+    const float dd = ft_dot(dir, dir);
+    return cc * dd - b * b > tol * dd;
+}
+
 // advance a lane until it needs an SDF evaluation (or is idle): everything in SdfScene.trace that
 // is not a Distance call.
 template <bool EXT>
@@ -1060,7 +1076,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
     const float piInv = 1.0f / 3.14159274101257324f;                   // Math.fs:28-30
     for (;;) {
         if (s.phase == PH_MARCH) {
-            if (s.len <= 0.0f) {                                       // SdfForm.fs:94 -> SdfScene.fs:10
+            if (s.len <= 0.0f || ft_never_enters(a.S, s.o, s.dir, s.eps)) {   // SdfForm.fs:94 -> SdfScene.fs:10; or every further step is known to miss
                 if (EXT && a.mode >= 2u) write_try_trace_miss(a, s);   // ValueNone of the tryTrace entries
                 else emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
                 s.phase = PH_IDLE;
@@ -1086,7 +1102,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             continue;
         }
         if (s.phase == PH_SHADOW) {
-            if (s.len <= 0.0f) {                                       // shadow ray missed: light arrives
+            if (s.len <= 0.0f || ft_never_enters(a.S, s.o, s.dir, s.eps)) {   // shadow ray missed (or can only miss): light arrives
                 sh_set3(FT_SH_LACC, sh_get3(FT_SH_LACC) + sh_get3(FT_SH_LINT) * *ft_sh(FT_SH_LCOS));   // SdfScene.fs:23
                 s.lidx += 1; s.phase = PH_LIGHTS;
                 continue;

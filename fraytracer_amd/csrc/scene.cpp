@@ -678,6 +678,67 @@ struct Flattener {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Support sphere of a form: a sphere (centre, radius) such that  value(form, p) < tau  implies  dist(p, sphere) < tau  for every
+// tau > 0 — so a ray that stays farther than epsilon from it can never "hit" (SdfForm.fs:98) and its march is known to end in a miss.
+// (kernels.hip ft_never_enters).  By structure, in double:
+//   primitive (exact signed distance)   a sphere around the shape, from its own parameters
+//   union      min of (a subset of) the children   ->  a sphere around the children's spheres
+//   subtract   Max(-b, a) >= a                     ->  a's sphere          (SdfForm.fs:46-47)
+//   intersect  the running Max starts at child 0   ->  child 0's sphere    (SdfForm.fs:60-63: later children may be skipped, never child 0)
+//   unionSmooth  -k ln(sum exp(-d_i / k)) >= min d_i - k ln n   ->  the children's spheres grown by k ln n (needs k > 0)
+// false: no finite sphere is known (degenerate parameters, k <= 0): the scene gets none and every ray marches to its end.
+// ------------------------------------------------------------------------------------------------
+struct Support { double c[3]; double r; };
+static bool finite3(const double v[3]) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+static bool enclose(const std::vector<Support>& ss, Support& out) {
+    if (ss.empty()) return false;
+    double c[3] = {0, 0, 0};
+    for (const Support& s : ss) for (int k = 0; k < 3; ++k) c[k] += s.c[k] / (double)ss.size();
+    double r = 0.0;
+    for (const Support& s : ss) {
+        const double d = std::sqrt((s.c[0] - c[0]) * (s.c[0] - c[0]) + (s.c[1] - c[1]) * (s.c[1] - c[1]) + (s.c[2] - c[2]) * (s.c[2] - c[2])) + s.r;
+        if (d > r) r = d;
+    }
+    out = Support{{c[0], c[1], c[2]}, r};
+    return finite3(out.c) && std::isfinite(out.r);
+}
+static bool supportOf(const Builder& b, int h, Support& out, int depth = 0) {
+    if (depth > 64 || !b.okForm(h)) return false;
+    const HostForm& f = b.forms[h];
+    const std::vector<float>& P = f.params;
+    auto V = [&](size_t i) { return Support{{(double)P[i], (double)P[i + 1], (double)P[i + 2]}, 0.0}; };
+    auto dist = [](const Support& a, const Support& c) { return std::sqrt((a.c[0] - c.c[0]) * (a.c[0] - c.c[0]) + (a.c[1] - c.c[1]) * (a.c[1] - c.c[1]) + (a.c[2] - c.c[2]) * (a.c[2] - c.c[2])); };
+    bool ok = false;
+    switch (f.kind) {
+    case HostForm::SPHERE: out = V(0); out.r = std::fabs((double)P[3]); ok = true; break;                       // params: c, r
+    case HostForm::CAPSULE: {                                                                                    // from, r, dir, dirInv
+        out = V(0); for (int k = 0; k < 3; ++k) out.c[k] += 0.5 * (double)P[4 + k];
+        out.r = 0.5 * std::sqrt((double)P[4] * P[4] + (double)P[5] * P[5] + (double)P[6] * P[6]) + std::fabs((double)P[3]); ok = true; break;
+    }
+    case HostForm::TORUS: out = V(0); out.r = std::fabs((double)P[3]) + std::fabs((double)P[7]); ok = true; break;   // c, R, n, r
+    case HostForm::TRIANGLE: {                                                                                   // v1, r | v2, - | v3, - | ...
+        const Support v1 = V(0), v2 = V(4), v3 = V(8);
+        Support c{{(v1.c[0] + v2.c[0] + v3.c[0]) / 3.0, (v1.c[1] + v2.c[1] + v3.c[1]) / 3.0, (v1.c[2] + v2.c[2] + v3.c[2]) / 3.0}, 0.0};
+        c.r = std::max(dist(c, v1), std::max(dist(c, v2), dist(c, v3))) + std::fabs((double)P[3]);
+        out = c; ok = true; break;
+    }
+    case HostForm::BOX: out = V(0); out.r = std::sqrt((double)P[4] * P[4] + (double)P[5] * P[5] + (double)P[6] * P[6]); ok = true; break;   // c, -, half
+    case HostForm::SUBTRACT: case HostForm::INTERSECT: return !f.kids.empty() && supportOf(b, f.kids[0], out, depth + 1);
+    case HostForm::UNION: case HostForm::SMOOTH: {
+        double grow = 0.0;
+        if (f.kind == HostForm::SMOOTH) {
+            if (!(f.strength > 0.0f) || !std::isfinite(f.strength)) return false;
+            grow = (double)f.strength * std::log((double)f.kids.size());
+        }
+        std::vector<Support> ss;
+        for (int k : f.kids) { Support s; if (!supportOf(b, k, s, depth + 1)) return false; s.r += grow; ss.push_back(s); }
+        return enclose(ss, out);
+    }
+    }
+    return ok && finite3(out.c) && std::isfinite(out.r);
+}
+
 bool flatten(const Builder& b, int object, const float bg[3], const int* lights, int nLights, FlatScene& out, std::string& err) {
     if (!b.okObject(object)) { err = "invalid object handle"; return false; }
     out = FlatScene{};
@@ -688,6 +749,12 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
     out.nearR2 = (fl.stageEnd > 0 && fl.nearR > 0.0 && fl.nearR < 1e29) ? (float)(fl.nearR * fl.nearR * (1.0 - 1e-5)) : 0.0f;
     out.fastQ = (fl.anyUnion && fl.unionFastQ) ? 1u : 0u;
+    // the sphere no hit can lie outside of (see supportOf): grown by what float32 evaluation may differ from the exact value, 0.1 % and 0.01
+    Support sup;
+    if (supportOf(b, b.objects[object].form, sup) && sup.r < 1e15 && std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]) < 1e15) {
+        out.escC[0] = (float)sup.c[0]; out.escC[1] = (float)sup.c[1]; out.escC[2] = (float)sup.c[2];
+        out.escR = (float)(sup.r * 1.001 + 0.01 + 1e-3 * (std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2])));
+    }
     // kernel variant: 1 = the program is only staged fast sphere runs + SMOOTH_FIN + SETLEAF
     bool lean = !out.instr.empty() && out.nMainInstr == out.instr.size();
     for (const FtInstr& in : out.instr) {

@@ -101,6 +101,7 @@ struct FlatScene {                                            // host copy of ev
     uint32_t nStage = 0;                                      // consts[0, nStage) is mirrored in LDS by every workgroup
     float nearR2 = 0.0f;                                      // see FtSceneDev::nearR2
     uint32_t fastQ = 0;                                       // see FtSceneDev::fastQ
+    float escC[3] = {0, 0, 0}, escR = -1.0f;                  // see FtSceneDev::escR (support sphere of the scene; -1: none)
     uint32_t fastPath = 0;
     float bg[3] = {0, 0, 0};
 };

@@ -119,6 +119,9 @@ typedef enum ft_option {
     FT_OPT_CHUNK = 8,             /* 64 (default): rays a wave takes per grab = one 8x8 tile; 32 / 16: half / quarter tiles (experiments) */
     FT_OPT_CULL = 9,              /* 1 (default): the smooth-union kernel drops, per wave and round, the children whose terms are below half an ulp
                                    * of the running sum in every ray of the wave (exact: the sum is unchanged bit for bit); 0: every child, every round */
+    FT_OPT_ESCAPE = 10,           /* 1 (default): a ray that can no longer come within epsilon of the scene's support sphere — outside it and heading away, or
+                                   * passing it by — ends as the miss its march is bound to end in, without further evaluations (same frame, fewer sdf_evals);
+                                   * 0: every ray marches until its Length is used up, as the reference does */
     FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's
@@ -251,6 +254,9 @@ int ft_scene_info_get(const ft_scene*, ft_scene_info* out);
  * ft_scene_grid_shape: cell_start[ncells+1], centers[3*ncells], lower[nitems], child[nitems] */
 int ft_scene_grid_shape(const ft_scene*, int32_t g, float info[6], int32_t counts[3], int32_t* n_cells, int32_t* n_items);
 int ft_scene_grid_dump(const ft_scene*, int32_t g, uint32_t* cell_start, float* centers, float* lower, int32_t* child);
+/* the scene's support sphere (centre xyz, radius): no point farther than epsilon from it can be a hit, which is what FT_OPT_ESCAPE relies on;
+ * radius < 0: none is known for this scene (degenerate shapes, a unionSmooth of strength <= 0) and every ray marches to its end */
+int ft_scene_support_sphere(const ft_scene*, float centre_radius[4]);
 
 /* math primitives of the device path, evaluated on the GPU: op 0 exp, 1 log, 2 sqrt, 3 a/b, 4 fast sqrt, 5 fast exp
  * (y = second operand, may be NULL otherwise).  Used by tests/test_math_parity.py. */

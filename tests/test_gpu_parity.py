@@ -363,6 +363,49 @@ def test_child_culling_is_exact_and_happens(gpu, oracle):
         gpu.set_option("cull", 1); gpu.set_option("tail_k", -1)
 
 
+def test_escape_shortcut_changes_no_pixel(gpu, oracle):
+    """FT_OPT_ESCAPE: a ray that can no longer come within epsilon of the scene's support sphere ends as a miss at once.  Frames, ray and hit
+    counters and flags are the oracle's with the shortcut on and off; with it on fewer evaluations are spent.  Scenes of every kernel variant,
+    the reference's two light types, explicit rays that start outside, inside, tangent to and pointing away from the sphere, and the
+    tryTrace entries (ValueNone on a miss)."""
+    cam = syn.default_camera()
+    cases = [("C3 lean", syn.config3(n=64, size=256)[0], 256, 64), ("C2", syn.config2(seed=4, size=128)[0], 128, 96),
+             ("Program.fs structure", syn.console_scene(n=120, size=160)[0], 160, 120), ("mixed nested", syn.mixed_nested()[0], 96, 96),
+             ("combinator zoo (calls)", syn.combinator_zoo()[0], 96, 80)]
+    try:
+        for name, scene, W, H in cases:
+            ds, os_ = both(gpu, oracle, scene)
+            want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array())
+            evals = {}
+            for esc in (1, 0):
+                gpu.set_option("escape", esc)
+                g, gst = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+                assert_bit_equal(g, want, f"{name}, escape {esc}")
+                check_counts(gst, ocnt)
+                evals[esc] = gst["sdf_evals"]
+            assert evals[1] < evals[0], (name, evals)
+            cx, cy, cz, R = ds.support_sphere()
+            assert R > 0
+            # explicit rays around the support sphere
+            rng = np.random.default_rng(11)
+            n = 400
+            o = (np.array([cx, cy, cz]) + rng.normal(size=(n, 3)) * R * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+            d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+            d[:50] = (np.array([cx, cy, cz], np.float32) - o[:50]); d[:50] /= np.linalg.norm(d[:50], axis=1, keepdims=True)   # straight at the centre
+            d[50:100] = -d[:50]                                                                                               # ... and straight away (origins differ)
+            d[100:110] *= np.float32(0.0)                                                                                     # a ray that does not move
+            d[110:120] *= np.float32(37.5)                                                                                    # non-unit directions
+            rays = np.concatenate([o, d, rng.uniform(0.5, 60.0, (n, 1)).astype(np.float32), np.full((n, 1), 0.01, np.float32)], axis=1).astype(np.float32)
+            for esc in (1, 0):
+                gpu.set_option("escape", esc)
+                with np.errstate(all="ignore"):
+                    assert_bit_equal(ds.trace_rays(rays)[0], os_.trace_rays(rays)[0], f"{name}: ray buffer, escape {esc}")
+                    gf, of = ds.form_try_trace(rays), os_.form_try_trace(rays)
+                    assert_bit_equal(gf[0] if isinstance(gf, tuple) else gf, of[0] if isinstance(of, tuple) else of, f"{name}: SdfForm.tryTrace, escape {esc}")
+    finally:
+        gpu.set_option("escape", 1)
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)

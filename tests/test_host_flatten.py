@@ -160,3 +160,51 @@ def test_host_side_mirrors_of_the_small_reference_functions(oracle):
     np.testing.assert_array_equal(moved, np.array([1, np.float32(2) + np.float32(0.6) * np.float32(2.5), np.float32(3) + np.float32(0.8) * np.float32(2.5), 0, 0.6, 0.8, 27.5, 0.01], np.float32))
     np.testing.assert_array_equal(ft.Ray.get(-0.01, r), r[0:3] + r[3:6] * np.float32(-0.01))
     np.testing.assert_array_equal(ft.Ray.setDirection((1, 0, 0), r)[3:6], [1, 0, 0])
+
+
+def _weird_scenes():
+    """scenes that stress the support-sphere rules: intersections whose later children are far bigger or far away, subtractions, nested smooth
+    unions, thin and obtuse triangles, boxes, a smooth union of non-sphere children"""
+    P = SdfForm.Primitive
+    mat = SdfMaterial.createSolid((0.5, 0.5, 0.5))
+    rng = syn.Rng(21)
+    mk = lambda form: SdfScene(SdfObject.create(mat, form), syn.BACKGROUND, syn.program_lights())
+    out = [mk(SdfForm.intersect([P.sphere((3, 0, 0), 1.0), P.sphere((0, 0, 0), 30.0), P.torus((40, 0, 0), (0, 1, 0), 5.0, 1.0)])),
+           mk(SdfForm.subtract(P.capsule((-2, 0, 0), (2, 1, 0), 0.4), P.sphere((50, 0, 0), 45.0))),
+           mk(SdfForm.unionSmooth(0.7, [SdfForm.unionSmooth(0.2, [P.sphere(rng.pointInBall(3.0), 0.3) for _ in range(6)]),
+                                        P.torus((1, 2, 0), (0, 0, 1), 1.5, 0.2), P.triangle((0, 0, 0), (5, 0.01, 0), (-4, 0.02, 0.1), 0.05),
+                                        P.box((-3, 0, 1), (0.5, 2.0, 0.1))])),
+           mk(SdfForm.union([P.triangle((0, 0, 0), (1, 0, 0), (0.5, 1e-3, 0), 0.01), P.sphere((10, 10, 10), 0.1), P.capsule((0, -5, 0), (0, -5.001, 0), 0.2)]))]
+    return out
+
+
+@pytest.mark.parametrize("make", [lambda: syn.config1()[0], lambda: syn.config2(boxes=True)[0], lambda: syn.config3(n=40)[0], lambda: syn.config5()[0],
+                                  lambda: syn.console_scene(n=60)[0], lambda: syn.mixed_nested()[0], lambda: syn.combinator_zoo()[0]]
+                         + [(lambda s=s: s) for s in _weird_scenes()])
+def test_support_sphere_holds_every_small_distance(host, oracle, make):
+    """FT_OPT_ESCAPE ends a ray as a miss once it can no longer come within epsilon of the scene's support sphere (scene.cpp supportOf).  That
+    is exact iff  Distance(p) < tau  implies  dist(p, sphere) < tau: checked here against the ORACLE's Distance on 60 000 points outside the
+    sphere, from just beyond it to 100 radii away (where the inequality is tightest: points near the sphere in every direction)."""
+    scene = make()
+    ds = host.scene(scene)
+    cx, cy, cz, R = ds.support_sphere()
+    assert R > 0 and np.isfinite(R)
+    O = oracle.Oracle()
+    obj = ft.realise(scene.Object, O, {})
+    rng = np.random.default_rng(5)
+    u = rng.normal(size=(60000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    beyond = np.concatenate([rng.uniform(0, 0.05, 20000), rng.uniform(0, 2.0, 20000), 10.0 ** rng.uniform(-2, 2, 20000)]) * R
+    pts = (np.array([cx, cy, cz]) + u * (R + beyond)[:, None]).astype(np.float32)
+    d = O.form_distance(O.object_form(obj), pts).astype(np.float64)
+    outside = np.linalg.norm(pts.astype(np.float64) - np.array([cx, cy, cz]), axis=1) - R
+    ok = np.isnan(d) | (d >= outside)                                  # NaN never compares below epsilon
+    assert ok.all(), (pts[~ok][:5], d[~ok][:5], outside[~ok][:5])
+
+
+def test_support_sphere_is_refused_where_it_cannot_be_proved(host):
+    P = SdfForm.Primitive
+    mat = SdfMaterial.createSolid((0.5, 0.5, 0.5))
+    weird = SdfScene(SdfObject.create(mat, SdfForm.unionSmooth(-0.5, [P.sphere((0, 0, 0), 1.0), P.sphere((2, 0, 0), 1.0)])), syn.BACKGROUND, [])
+    assert host.scene(weird).support_sphere()[3] < 0
+    big = SdfScene(SdfObject.create(mat, P.sphere((0, 0, 0), 3e20)), syn.BACKGROUND, [])
+    assert host.scene(big).support_sphere()[3] < 0
