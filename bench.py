@@ -167,6 +167,8 @@ def main():
         for d in lanes:
             st_ = d.collect_stats()
             tot = st_ if tot is None else {k: (min(tot[k], st_[k]) if k == "shader_mhz" else tot[k] + st_[k]) for k in tot}
+        for k in ("tail_fraction", "culled_fraction"):
+            tot[k] /= len(lanes)
         return tot
 
     def step():
@@ -180,6 +182,14 @@ def main():
             pipe.drain()
             dist.barrier()
         torch.cuda.synchronize()
+
+    # The REFERENCE's work for this rank's share of the frame: one untimed launch with the escape shortcut off marches every ray to its end as
+    # the reference does (its counters are the oracle's); the roofline prices that work, the timed launches run the product's defaults
+    dev.set_option("escape", 0)
+    ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
+    torch.cuda.synchronize()
+    ref = ds.collect_stats()
+    dev.set_option("escape", 1)
 
     if pipe is not None:                          # both render lanes settle (lean-kernel placement is timed per context) before anything counts
         for d_ in lanes:
@@ -294,13 +304,17 @@ def main():
         CW = 4000
         csize = ft.ImageSize(CW, CW)
         cbuf = torch.empty((CW, CW, 3), dtype=torch.float32, device="cuda")
+        dev.set_option("escape", 0)                # the reference's evaluation count: every ray marched to its end
+        cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
+        torch.cuda.synchronize(); cref = cds.collect_stats()
+        dev.set_option("escape", 1)
         cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
         torch.cuda.synchronize(); cds.collect_stats()
         for _ in range(args.steps):
             cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
         torch.cuda.synchronize()
         cst = cds.collect_stats()
-        console = {"stats": cst, "frame": cbuf, "scene": cscene, "W": CW}
+        console = {"stats": cst, "frame": cbuf, "scene": cscene, "W": CW, "ref_evals": cref["sdf_evals"], "ref_kernel_ms": cref["kernel_ms"]}
 
     # FT_OPT_MATH = glibc: the same K frames with MathF.Exp / Log as this host's C runtime computes them (glibc's expf / logf restated on
     # the GPU, csrc/ft_libm.h) — the arithmetic the reference's CPU path would use on this very machine.  Checked further down against the
@@ -335,8 +349,8 @@ def main():
         del fixed_frame, a64, b64
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"]],
-                       dtype=torch.int64, device="cuda")
+    cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"],
+                        ref["sdf_evals"], ref["hits_primary"], ref["rays_shadow"]], dtype=torch.int64, device="cuda")
     kms = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device="cuda")
     per_rank = None
     if use_dist:
@@ -352,7 +366,7 @@ def main():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    rays_primary, rays_shadow, evals, hits, flags = (int(v) for v in cnt.tolist())
+    rays_primary, rays_shadow, evals, hits, flags, ref_evals, ref_hits, ref_shadow = (int(v) for v in cnt.tolist())
 
     if rank == 0:
         rays = rays_primary + rays_shadow
@@ -363,9 +377,16 @@ def main():
         traffic, traffic_src, valu_busy = profile_figures(build["src"], "ft_trace_kernel_smooth_spheres ") if (W == 4096 and world == 1) else (None, None, None)
         if traffic_src is None:
             traffic_src = "no profiles/*_summary.txt carries the stamp of this build (src=%s): traffic / valu_busy_pmc not quoted" % build["src"]
-        flops_launch = algorithmic_flops(st, args.spheres) / args.steps
-        launch_s = st["kernel_ms"] / 1e3 / args.steps
+        # algorithmic = the reference's work: every evaluation of every ray marched to its end, every child in every evaluation (whole job; at
+        # N > 1 the kernel time is the slowest rank's, so the figure is priced per rank share)
+        flops_launch = algorithmic_flops({"sdf_evals": ref_evals, "hits_primary": ref_hits, "rays_shadow": ref_shadow}, args.spheres) / world
+        launch_s = float(kms.item()) / 1e3 / args.steps
         achieved = flops_launch / launch_s / 1e12
+        # executed = what the kernel did: fewer evaluations (escape shortcut), and in each only the children that were not culled
+        culled = st["culled_fraction"]
+        flops_exec = algorithmic_flops({"sdf_evals": evals // args.steps, "hits_primary": hits // args.steps, "rays_shadow": rays_shadow // args.steps},
+                                       args.spheres * (1.0 - culled)) / world
+        achieved_exec = flops_exec / launch_s / 1e12
         out = {
             "metric": "Mrays/s (primary+secondary) at 4096x4096; max per-pixel |delta| vs F# ref "
                       "(delta is measured against the CPU oracle: F# parity is unpinned, DESIGN.md section 2)",
@@ -375,23 +396,30 @@ def main():
             "config": {"workload": f"C3: unionSmooth(0.25) of {args.spheres} spheres, {W}x{H}, 1 spp, 1 directional light "
                                    "(shadow rays = secondary rays), eps 0.01, ray length 30",
                        "rays_per_frame": rays // args.steps, "primary": rays_primary // args.steps,
-                       "shadow": rays_shadow // args.steps, "sdf_evals_per_frame": evals // args.steps,
+                       "shadow": rays_shadow // args.steps, "sdf_evals_per_frame": ref_evals,
+                       "sdf_evals_executed_per_frame": evals // args.steps, "children_culled_fraction": round(culled, 4),
                        "parallelism": f"column stripes of {STRIPE} over {world} GPU(s) + 1 RCCL gather" if world > 1 else "1 GPU",
                        "nan_or_cap_flags": flags,
                        "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4),
                        "shader_mhz": round(st["shader_mhz"], 1)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_executed": round(achieved_exec, 3), "frac_executed": round(achieved_exec / VALU_PEAK_TLANEOPS, 4),
                          "valu_busy_pmc": valu_busy,
                          "kernel": "ft_trace_kernel_smooth_spheres",
                          "kernel_ms": round(launch_s * 1e3, 3),
                          "algorithmic_flops_per_launch": int(flops_launch),
                          "shader_mhz": round(st["shader_mhz"], 1),
                          "shader_Gcycles_per_launch": round(launch_s * st["shader_mhz"] * 1e6 / 1e9, 4),
+                         "work_note": "achieved / frac price the REFERENCE's work (SURVEY.md section 8d: every SDF evaluation of every ray marched to its end, all "
+                                      "children in each; counters of an untimed launch with the escape shortcut off = the oracle's): an algorithmic figure.  "
+                                      "achieved_executed / frac_executed price what the kernel executes — it ends rays that can no longer reach the scene's "
+                                      "support sphere (sdf_evals_executed_per_frame) and drops, per wave and round, the children whose terms are below half "
+                                      "an ulp of the running sum (children_culled_fraction); both are exact (DESIGN.md section 4).  valu_busy_pmc is the hardware figure",
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
                                  "flop each although a correctly rounded sqrt / reproducible exp need 4 / 11 instructions: 26 VALU instructions "
                                  "per child against 13 algorithmic flops (the near loop's root and strength product use output modifiers inside a "
-                                 "verified MODE region, DESIGN.md section 4), issued at 2.37 cycles each at this occupancy "
+                                 "verified MODE region, DESIGN.md section 4), issued at ~2.4 cycles each "
                                  "(DESIGN.md section 5: at the instruction-issue floor of this mix). peak is priced at 2.4 GHz; the chip "
                                  "sustains shader_mhz under this load (power management), which is the box-to-box spread. "
                                  "HBM traffic = 12 B/pixel output."},
@@ -457,14 +485,16 @@ def program_fs_block(console, cam, steps, build_src):
     # candidates where the reference scans `union_candidates` (both from the oracle's counters of the sampled columns)
     executed = dict(cnt); executed["union_candidates"] = cnt["union_tested"]
     flops_per_eval_executed = union_algorithmic_flops(executed) / max(1, cnt["root_evals"])
-    evals = cst["sdf_evals"] / steps
+    evals = cst["sdf_evals"] / steps                      # executed: rays that can no longer reach the scene's support sphere end at once (FT_OPT_ESCAPE)
+    evals_ref = console["ref_evals"]                      # the reference's: every ray marched to its end (one launch with the shortcut off)
     kernel_s = cst["kernel_ms"] / 1e3 / steps
     rays = (cst["rays_primary"] + cst["rays_shadow"]) / steps
-    achieved = flops_per_eval * evals / kernel_s / 1e12
+    achieved = flops_per_eval * evals_ref / kernel_s / 1e12
     achieved_executed = flops_per_eval_executed * evals / kernel_s / 1e12
     _, prof_src, valu_busy = profile_figures(build_src, "# case: Program.fs scene 4000^2")
     return {"workload": f"Program.fs scene, {CW}x{CW}, 1 spp, directional + point light", "value": round(rays / kernel_s / 1e6, 1), "unit": "Mrays/s",
-            "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals),
+            "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals_ref),
+            "sdf_evals_executed_per_frame": int(evals), "kernel_ms_with_every_ray_marched_to_its_end": round(console["ref_kernel_ms"], 3),
             "lane_utilisation": round(cst["sdf_evals"] / (64.0 * max(1, cst["wave_evals"])), 4), "shader_mhz": round(cst["shader_mhz"], 1),
             "max_abs_delta_vs_oracle": delta, "pixels_compared_with_oracle": int(img.shape[0] * img.shape[1]),
             "roofline": {"bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
@@ -475,8 +505,9 @@ def program_fs_block(console, cam, steps, build_src):
                          "candidates_per_eval_reference": round(cnt["union_candidates"] / max(1, cnt["root_evals"]), 2),
                          "candidates_per_eval_executed": round(cnt["union_tested"] / max(1, cnt["root_evals"]), 2),
                          "primitive_evals_per_eval": round(sum(cnt["prim"]) / max(1, cnt["root_evals"]), 2),
-                         "note": "frac_reference_work prices the reference's own work (it scans a cell's whole candidate list, 13 flops per candidate): an "
-                                 "algorithmic speed-up figure, not a hardware fraction.  frac_executed prices what the kernel executes: it leaves the sorted list "
+                         "note": "frac_reference_work prices the reference's own work (every ray marched to its end, a cell's whole candidate list scanned, 13 flops per "
+                                 "candidate): an algorithmic speed-up figure, not a hardware fraction.  frac_executed prices what the kernel executes: rays that can no "
+                                 "longer reach the scene's support sphere end at once (sdf_evals_executed_per_frame; exact) and the walk leaves the sorted list "
                                  "at the first failing LowerBound test (exact), i.e. candidates_per_eval_executed of them.  valu_busy_pmc: PMC of a committed "
                                  "profile of this same build and size, or null"}}
 

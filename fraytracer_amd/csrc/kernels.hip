@@ -760,16 +760,16 @@ __device__ __forceinline__ void ft_eval_coop(const FtSceneDev& S, const f3 p, fl
 // rays of a wave are neighbours (burst refill: one 8x8 tile at a time), so whether a child is such a no-op can be decided ONCE PER WAVE
 // AND ROUND from bounds that hold for all of its rays; in the C3 frame a third of all (child, evaluation) pairs go that way.
 //
-// Once per round, all 64 lanes (also those without a ray) take part: q0 = the query point of the first lane that has one, rho >= the
+// Once per round, all 64 lanes (also those without a ray) take part: q0 = a point in the middle of the rays' query points, rho >= the
 // distance of every such point from q0.  Lane k of pass j looks at child i = 64 j + k (centre c, radius r) and computes, in plain f32
 // with generous slack,  dlo <= |c - p| - r <= dhi  for every ray's p (triangle inequality: | |c - q0| - r +- rho |), hence
 //     low_i  <=  the child's term in every lane          (2^(si dhi log2e - 0.02) by v_exp_f32)
-//     n_i    >=  the exponent n of the term in every lane (every exponential here returns less than 2^(n+1), n = round(t log2 e), t <= si dlo)
+//     x_i    >=  log2 of the child's term in every lane    (t = si d <= si dlo, the exponentials are within an ulp of e^t: term < 2^(x_i + 0.02))
 // and an exclusive prefix sum over the children in list order gives  Slow_i  <=  the running sum every lane holds in front of child i:
 // the sum of the lower bounds of ALL earlier children, times (1 - 2^-8), which covers the rounding of that prefix sum, of the lanes'
 // own sequential sums (256 x 2^-24) and of their exponentials (< 1 ulp), and the culled children among them, whose lower bounds are
 // counted although their terms were absorbed (they add up to less than 255 x 2^-24 of the sum).  Child i is dropped for this wave and
-// round iff Slow_i is a normal number and  n_i + 1 <= exponent(Slow_i) - 24,  i.e.  term < 2^(n_i + 1) <= half an ulp of any float
+// round iff Slow_i is a normal number and  x_i + 0.02 <= exponent(Slow_i) - 24,  i.e.  term < half an ulp of any float
 // >= Slow_i — by induction over the list the running sums are then exactly the reference's.  The first child is never dropped
 // (Slow_0 = 0); NaN, infinite or huge points switch the pass off.  Survivors keep their order: their parameter records are copied,
 // compacted, into the wave's own LDS row, which the unchanged sphere loops then read instead of the staged constants.
@@ -799,7 +799,15 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
     const bool bad = !(m < FT_FAST_P_MAX) || p.x != p.x || p.y != p.y || p.z != p.z;
     if (__ballot(active && bad) != 0ull) return FT_CULL_NONE;         // such evaluations take the exact loop anyway
     const uint32_t lane = threadIdx.x & 63u;
-    const f3 q0 = ft_readlane3(p, __ffsll((long long)am) - 1);
+    // centre: half way between the first ray's point and the point farthest from it (a cheap stand-in for the smallest enclosing ball:
+    // the points of a tile spread mostly along the rays); rho: the largest distance of any ray's point from that centre
+    const f3 q00 = ft_readlane3(p, __ffsll((long long)am) - 1);
+    const float fx = p.x - q00.x, fy = p.y - q00.y, fz = p.z - q00.z;
+    const float far2 = active ? (fx * fx + fy * fy) + fz * fz : 0.0f;
+    const float farMax = ft_wave_max_all(far2);
+    const unsigned long long fm = __ballot(active && far2 == farMax);  // never empty: the maximum is some active lane's (kept safe all the same)
+    const f3 q01 = ft_readlane3(p, __ffsll((long long)(fm != 0ull ? fm : am)) - 1);
+    const f3 q0 = mk3(0.5f * (q00.x + q01.x), 0.5f * (q00.y + q01.y), 0.5f * (q00.z + q01.z));
     const float ex = p.x - q0.x, ey = p.y - q0.y, ez = p.z - q0.z;
     const float rho2 = ft_wave_max_all(active ? (ex * ex + ey * ey) + ez * ez : 0.0f);
     const float rho = __builtin_amdgcn_sqrtf(rho2) * 1.001f + 1e-6f;   // >= |p - q0| of every active lane (v_sqrt_f32: 1 ulp)
@@ -822,9 +830,9 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
         float excl = __shfl_up(incl, 1, 64); if (lane == 0u) excl = 0.0f;
         const float slow = (carry + excl) * 0.99609375f;              // 1 - 2^-8
         const uint32_t sbits = __float_as_uint(slow);
-        const float x = __builtin_fminf(__builtin_fmaxf(si * dlo * 1.44269504f, -1000.0f), 1000.0f);
-        const int nUp = (int)__builtin_floorf(x + 0.52f) + 1;
-        const bool drop = have && x == x && sbits >= 0x00800000u && sbits < 0x7f800000u && nUp + 1 <= (int)(sbits >> 23) - 127 - 24;
+        const float x = __builtin_fminf(__builtin_fmaxf(si * dlo * 1.44269504f, -1000.0f), 1000.0f);   // log2 of the largest term any lane can compute ...
+        // ... up to the rounding of t and of the exponential (< 1 ulp), both far inside the 0.02; half an ulp of a float in [2^e, 2^(e+1)) is 2^(e-24)
+        const bool drop = have && x == x && sbits >= 0x00800000u && sbits < 0x7f800000u && x + 0.02f <= (float)((int)(sbits >> 23) - 127 - 24);
         const bool keep = have && !drop;
         const unsigned long long km = __ballot(keep);
         if (keep) dst[kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = prm;
@@ -1076,7 +1084,9 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
     const float piInv = 1.0f / 3.14159274101257324f;                   // Math.fs:28-30
     for (;;) {
         if (s.phase == PH_MARCH) {
-            if (s.len <= 0.0f || ft_never_enters(a.S, s.o, s.dir, s.eps)) {   // SdfForm.fs:94 -> SdfScene.fs:10; or every further step is known to miss
+            // SdfForm.fs:94 -> SdfScene.fs:10; or every further step is known to miss (EXTENSION glass: a path inside a body marches on
+            // -Distance, which is below epsilon everywhere outside the support sphere — the shortcut is for paths outside bodies only)
+            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps))) {
                 if (EXT && a.mode >= 2u) write_try_trace_miss(a, s);   // ValueNone of the tryTrace entries
                 else emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
                 s.phase = PH_IDLE;
@@ -1102,7 +1112,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             continue;
         }
         if (s.phase == PH_SHADOW) {
-            if (s.len <= 0.0f || ft_never_enters(a.S, s.o, s.dir, s.eps)) {   // shadow ray missed (or can only miss): light arrives
+            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps))) {   // shadow ray missed (or can only miss): light arrives
                 sh_set3(FT_SH_LACC, sh_get3(FT_SH_LACC) + sh_get3(FT_SH_LINT) * *ft_sh(FT_SH_LCOS));   // SdfScene.fs:23
                 s.lidx += 1; s.phase = PH_LIGHTS;
                 continue;

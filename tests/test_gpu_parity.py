@@ -384,6 +384,12 @@ def test_escape_shortcut_changes_no_pixel(gpu, oracle):
                 check_counts(gst, ocnt)
                 evals[esc] = gst["sdf_evals"]
             assert evals[1] < evals[0], (name, evals)
+            if name == "C2":                                           # EXTENSIONS on the same scene: AO rays (not shortened) and 4 samples per pixel
+                kw = dict(spp=4, ao_samples=3, ao_radius=0.7)
+                want_x = os_.render(EPS, LEN, W, H, cam.as_array(), **kw)[0]
+                for esc in (1, 0):
+                    gpu.set_option("escape", esc)
+                    assert_bit_equal(ds.render(EPS, LEN, ft.ImageSize(W, H), cam, **kw)[0], want_x, f"{name} with AO and 4 spp, escape {esc}")
             cx, cy, cz, R = ds.support_sphere()
             assert R > 0
             # explicit rays around the support sphere
@@ -402,6 +408,17 @@ def test_escape_shortcut_changes_no_pixel(gpu, oracle):
                     assert_bit_equal(ds.trace_rays(rays)[0], os_.trace_rays(rays)[0], f"{name}: ray buffer, escape {esc}")
                     gf, of = ds.form_try_trace(rays), os_.form_try_trace(rays)
                     assert_bit_equal(gf[0] if isinstance(gf, tuple) else gf, of[0] if isinstance(of, tuple) else of, f"{name}: SdfForm.tryTrace, escape {esc}")
+        # EXTENSION glass: a path inside a body marches on -Distance (below epsilon everywhere outside the support sphere): only paths
+        # outside bodies may take the shortcut (a fuzz scene with 7 bounces found the difference)
+        scene5 = syn.config5(size=96)[0]
+        ds5, os5 = both(gpu, oracle, scene5)
+        kw = dict(spp=4, spectral=4, max_bounces=6)
+        want5, ocnt5 = os5.render(EPS, LEN, 96, 96, cam.as_array(), **kw)
+        for esc in (1, 0):
+            gpu.set_option("escape", esc)
+            g5, gst5 = ds5.render(EPS, LEN, ft.ImageSize(96, 96), cam, **kw)
+            assert_bit_equal(g5, want5, f"glass, escape {esc}")
+            assert gst5["rays_ext"] == ocnt5["rays_ext"] and gst5["hits_primary"] == ocnt5["hits_primary"]
     finally:
         gpu.set_option("escape", 1)
 
