@@ -204,7 +204,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 // tables behind that, 8-byte aligned (kernels.hip ft_libm_lds_offset)
 // (kernels.hip ft_libm_lds_offset); the lean kernel keeps one row of FT_COOP_SEG floats per wave behind everything (16-byte aligned) for
 // the latency mode (kernels.hip ft_coop_lds_offset)
-#define FT_COOP_SEG_FLOATS 1024               // = FT_CULL_ROW (kernels.hip): 256 float4 records of culled children; its first 256 floats serve the latency mode
+#define FT_COOP_SEG_FLOATS FT_CULL_ROW        // the wave's row of culled children's records (ft_kernels.h); its first 256 floats serve the latency mode
 // traceLaunch: the lean trace kernel keeps its accumulator in a register and is launched with nSlots = 0 (launchTrace) — 2 KB per workgroup
 // that decide between 6 and 7 resident workgroups per CU; every other user of a lean scene (ft_eval_distance) runs the general interpreter
 size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false) {

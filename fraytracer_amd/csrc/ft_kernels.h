@@ -18,6 +18,11 @@
 #define FT_SH_ROWS 13         // hit position, normal, accumulated light, current light's intensity (3 each), its cosine
 #define FT_LDS_SH_BASE (FT_LDS_CNT_WORDS + FT_LDS_DBG_ROWS * FT_BLOCK)
 #define FT_LDS_HDR_FLOATS (FT_LDS_SH_BASE + FT_SH_ROWS * FT_BLOCK)
+// lean kernel: every wave owns a row of FT_CULL_MAX float4 records behind everything else (kernels.hip "Exact child culling").  With 256 staged
+// spheres a workgroup then needs 34 304 bytes of LDS: four per CU.  224 records would let a fifth in, and lose: the LAST children of a union
+// are the ones dropped most often (the running sum is largest in front of them) — C3 4096^2 34.3 ms at 256, 36.5 at 224
+#define FT_CULL_MAX 256
+#define FT_CULL_ROW (4 * FT_CULL_MAX)
 
 struct FtRenderArgs {
     FtSceneDev S;

@@ -775,8 +775,8 @@ __device__ __forceinline__ void ft_eval_coop(const FtSceneDev& S, const f3 p, fl
 // compacted, into the wave's own LDS row, which the unchanged sphere loops then read instead of the staged constants.
 // Cost: ~250 wave-instructions per round against 26 per child and ray saved.
 // ------------------------------------------------------------------------------------------------
-#define FT_CULL_MAX 256                        // children per culling pass (the wave's LDS row: FT_CULL_MAX float4); a longer run's tail is evaluated in full
-#define FT_CULL_ROW (4 * FT_CULL_MAX)          // floats; the row's first FT_COOP_SEG floats double as the latency mode's row (never used in the same round)
+// FT_CULL_MAX (ft_kernels.h): children per culling pass = float4 records of the wave's LDS row; a longer run's tail is evaluated in full.
+// FT_CULL_ROW: floats of that row; its first FT_COOP_SEG floats double as the latency mode's row (never used in the same round).
 #define FT_CULL_MIN 32u                        // runs shorter than this are not worth the pass
 #define FT_CULL_NONE 0xffffffffu
 __device__ __forceinline__ f3 ft_readlane3(f3 v, int l) {
