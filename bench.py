@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", "--no-spp4", dest="no_spp4", action="store_true",
                     help="skip the side measurements (4 spp, two lanes, host output, primary + AO target, Program.fs scene)")
+    ap.add_argument("--no-reference-launch", action="store_true",
+                    help="profiling passes (tools/profile.sh): skip the untimed launch that counts the reference's evaluations, so that every launch of the "
+                         "trace kernel in the profile is a timed one; the roofline then prices the executed evaluation count")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
     ap.add_argument("--cpu-columns", type=int, default=0,
@@ -185,11 +188,13 @@ def main():
 
     # The REFERENCE's work for this rank's share of the frame: one untimed launch with the escape shortcut off marches every ray to its end as
     # the reference does (its counters are the oracle's); the roofline prices that work, the timed launches run the product's defaults
-    dev.set_option("escape", 0)
-    ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
-    torch.cuda.synchronize()
-    ref = ds.collect_stats()
-    dev.set_option("escape", 1)
+    ref = None
+    if not args.no_reference_launch:
+        dev.set_option("escape", 0)
+        ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
+        torch.cuda.synchronize()
+        ref = ds.collect_stats()
+        dev.set_option("escape", 1)
 
     if pipe is not None:                          # both render lanes settle (lean-kernel placement is timed per context) before anything counts
         for d_ in lanes:
@@ -304,7 +309,9 @@ def main():
         CW = 4000
         csize = ft.ImageSize(CW, CW)
         cbuf = torch.empty((CW, CW, 3), dtype=torch.float32, device="cuda")
-        dev.set_option("escape", 0)                # the reference's evaluation count: every ray marched to its end
+        dev.set_option("escape", 0)                # the reference's evaluation count: every ray marched to its end (second launch: warm)
+        cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
+        torch.cuda.synchronize(); cds.collect_stats()
         cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
         torch.cuda.synchronize(); cref = cds.collect_stats()
         dev.set_option("escape", 1)
@@ -350,7 +357,8 @@ def main():
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"],
-                        ref["sdf_evals"], ref["hits_primary"], ref["rays_shadow"]], dtype=torch.int64, device="cuda")
+                        *((ref["sdf_evals"], ref["hits_primary"], ref["rays_shadow"]) if ref is not None else
+                          (st["sdf_evals"] // args.steps, st["hits_primary"] // args.steps, st["rays_shadow"] // args.steps))], dtype=torch.int64, device="cuda")
     kms = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device="cuda")
     per_rank = None
     if use_dist:

@@ -1065,15 +1065,16 @@ __device__ __forceinline__ void write_ray(float* o, f3 origin, f3 dir, float len
 // no evaluation along it can be below eps (SdfForm.fs:98), so its march ends in a miss whatever the steps are: the lane takes that exit at
 // once (FT_OPT_ESCAPE).  Outside and heading away (the distance to the centre only grows), or outside and passing by (closest approach
 // |w|^2 - b^2 / |dir|^2 beyond the radius); 4e-6 |w|^2 covers the rounding of the three dot products.  Any NaN: "may still come".
-__device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o, const f3 dir, float eps) {
-    if (!(S.escR >= 0.0f)) return false;
+// Only for rays whose remaining march stays where float32 cannot overflow (Length < 1e9, |dir| < 1e6, distance from the sphere < 1e15): there
+// every skipped evaluation is finite, so no NaN flag (SdfForm.fs: a NaN distance never terminates; flagged by the kernel and the oracle) is lost.
+__device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o, const f3 dir, float eps, float len) {
+    if (!(S.escR >= 0.0f) || !(len < 1e9f)) return false;
     const f3 w = o - mk3(S.escC[0], S.escC[1], S.escC[2]);
     const float re = S.escR + eps;
-    const float ww = ft_dot(w, w), cc = ww - re * re, tol = 4e-6f * ww;
-    if (!(cc > tol)) return false;                                     // inside, or too close to tell
+    const float ww = ft_dot(w, w), cc = ww - re * re, tol = 4e-6f * ww, dd = ft_dot(dir, dir);
+    if (!(cc > tol) || !(ww < 1e30f) || !(dd < 1e12f)) return false;   // inside, too close to tell, or reaching too far for the argument above
     const float b = ft_dot(w, dir);
     if (b >= 0.0f) return true;
-    const float dd = ft_dot(dir, dir);
     return cc * dd - b * b > tol * dd;
 }
 
@@ -1086,7 +1087,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
         if (s.phase == PH_MARCH) {
             // SdfForm.fs:94 -> SdfScene.fs:10; or every further step is known to miss (EXTENSION glass: a path inside a body marches on
             // -Distance, which is below epsilon everywhere outside the support sphere — the shortcut is for paths outside bodies only)
-            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps))) {
+            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {
                 if (EXT && a.mode >= 2u) write_try_trace_miss(a, s);   // ValueNone of the tryTrace entries
                 else emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
                 s.phase = PH_IDLE;
@@ -1112,7 +1113,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             continue;
         }
         if (s.phase == PH_SHADOW) {
-            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps))) {   // shadow ray missed (or can only miss): light arrives
+            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {   // shadow ray missed (or can only miss): light arrives
                 sh_set3(FT_SH_LACC, sh_get3(FT_SH_LACC) + sh_get3(FT_SH_LINT) * *ft_sh(FT_SH_LCOS));   // SdfScene.fs:23
                 s.lidx += 1; s.phase = PH_LIGHTS;
                 continue;

@@ -54,7 +54,7 @@ for name, scene, n, *rest in cases:
         t_host = time.perf_counter() - t0
     print(json.dumps({"scene": name, "kernel_ms": round(ms, 3), "Mrays/s": round(rays / ms / 1e3, 2),
                       "rays": int(rays), "evals_per_ray": round(st["sdf_evals"] / reps / rays, 2),
-                      "lane_util": round(st["sdf_evals"] / (64.0 * st["wave_evals"]), 4),
+                      "lane_util": round(st["sdf_evals"] / (64.0 * st["wave_evals"]), 4), "culled_fraction": round(st["culled_fraction"], 4),
                       "host_output_ms": round(t_host * 1e3, 2), "Mrays/s_incl_pcie": round(rays / t_host / 1e6, 2),
                       "scene_build_s": round(t_build, 3), "info": ds.info()}), flush=True)
     del buf

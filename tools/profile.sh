@@ -4,7 +4,7 @@
 # Writes gpurun_out/prof_<tag>/{trace,pmc_sq,pmc_sq2,pmc_fetch,pmc_write}; copy the summaries to profiles/.
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 3 --warmup 1 --no-cpu-baseline --no-side}
+ARGS=${*:---steps 3 --warmup 1 --no-cpu-baseline --no-side --no-reference-launch}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
