@@ -16,7 +16,10 @@ frame k+1 renders; all K frames are complete on rank 0 when the timed region end
 
 Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the f32 VALU peak
 (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s; no FMA contraction is
-allowed by the parity requirement); `cpu_baseline` times the CPU oracle (a C++ restatement of the
+allowed by the parity requirement).  `roofline.achieved / frac` price the REFERENCE's work as SURVEY.md §8d defines it — every evaluation of
+every ray marched until its Length is used up, all children in each; those counters come from one untimed launch with the escape shortcut
+off and equal the oracle's — while the timed launches run the product's defaults, which execute less, exactly (child
+culling, escape shortcut); `achieved_executed / frac_executed` price what ran, `valu_busy_pmc` is the hardware figure.  `cpu_baseline` times the CPU oracle (a C++ restatement of the
 F# CPU path — NOT the F# program) on a bounded sample of the same frame on this host's cores.
 """
 import argparse

@@ -2,7 +2,8 @@
 """Differential fuzzing aimed at the lean kernel's child culling: random smooth unions of spheres (32 - 400 children, strengths 0.03 - 1.5, radii and
 spreads over two decades) seen by random cameras — far away, close by, inside the cloud — on wide, low frames (a fine pixel pitch keeps the rays of a
 wave together, which is when children are dropped).  HIP path against the CPU oracle, float for float and counter for counter, with the pass on; the
-share of dropped (child, ray) pairs is reported.  Usage: python tools/fuzz_cull.py [first_seed] [count]"""
+share of dropped (child, ray) pairs is reported.  `wide`: scene extents from 0.1 to 3000 and strengths from 0.03 to 100 (the slack of the pass's bounds is absolute: large coordinates and weak
+unions are where it is smallest relative to the arithmetic's own rounding).  Usage: python tools/fuzz_cull.py [first_seed] [count] [wide]"""
 import json
 import os
 import sys
@@ -18,6 +19,7 @@ from oracle import binding as ob
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 dev = ft.Device(0)
 from _opts import apply_env_options
 applied = apply_env_options(dev)
@@ -28,8 +30,9 @@ t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(32, 401))
-    spread = float(10.0 ** rng.uniform(-0.5, 1.0))
-    strength = float(10.0 ** rng.uniform(-1.5, 0.18))
+    spread = float(10.0 ** (rng.uniform(-1.0, 3.5) if wide else rng.uniform(-0.5, 1.0)))
+    strength = float(10.0 ** rng.uniform(-1.5, 0.18)) * (spread if wide and rng.random() < 0.7 else 1.0)
+    strength = min(strength, 100.0)
     rmax = float(spread * 10.0 ** rng.uniform(-1.5, -0.5))
     c = rng.normal(size=(n, 3)) * spread * 0.5
     forms = [SdfForm.Primitive.sphere(tuple(float(v) for v in c[i]), float(rng.uniform(0.2, 1.0) * rmax)) for i in range(n)]
@@ -56,7 +59,7 @@ for seed in range(first, first + count):
     if (seed - first + 1) % 25 == 0:
         print(f"... {seed - first + 1} scenes, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
 cf = np.array(culled)
-print(json.dumps({"options": applied, "build": ft.build_info()["src"], "first_seed": first, "scenes": count, "lean_scenes": int(lean), "rays": int(rays),
+print(json.dumps({"options": applied, "build": ft.build_info()["src"], "first_seed": first, "scenes": count, "wide": wide, "lean_scenes": int(lean), "rays": int(rays),
                   "culled_fraction": {"mean": round(float(cf.mean()), 4), "median": round(float(np.median(cf)), 4), "max": round(float(cf.max()), 4),
                                       "scenes_above_10_percent": int((cf > 0.1).sum())},
                   "mismatching_scenes": len(bad), "mismatches": bad[:20], "seconds": round(time.time() - t0, 1)}))
