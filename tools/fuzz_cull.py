@@ -45,7 +45,7 @@ for seed in range(first, first + count):
     cam = Camera.lookAt(Position=tuple(float(v) for v in pos), LookAt=tuple(float(v) for v in rng.normal(size=3) * spread * 0.2), Up=(0.0, 1.0, 0.0),
                         Lens=Lens.create(float(rng.uniform(20.0, 90.0))))
     W, H = int(rng.choice([1024, 2048, 4096])), int(rng.choice([8, 16, 24]))
-    eps = float(10.0 ** rng.uniform(-3.0, -1.5))
+    eps = float(10.0 ** rng.uniform(-3.0, -1.5)) * (max(1.0, spread / 3.0) if wide else 1.0)      # (a step count that stays bounded at large extents)
     length = float(spread * rng.uniform(2.0, 40.0))
     ds = dev.scene(scene)
     lean += ds.info()["fast_path"] == 1
@@ -56,7 +56,7 @@ for seed in range(first, first + count):
     if not same or any(st[k] != cnt[k] for k in keys):
         bad.append((seed, int((g.view(np.uint32) != o.view(np.uint32)).sum()), {k: (st[k], cnt[k]) for k in keys if st[k] != cnt[k]}))
     culled.append(st["culled_fraction"]); rays += st["rays_primary"] + st["rays_shadow"]
-    if (seed - first + 1) % 25 == 0:
+    if (seed - first + 1) % (5 if wide else 25) == 0:
         print(f"... {seed - first + 1} scenes, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
 cf = np.array(culled)
 print(json.dumps({"options": applied, "build": ft.build_info()["src"], "first_seed": first, "scenes": count, "wide": wide, "lean_scenes": int(lean), "rays": int(rays),
