@@ -415,6 +415,7 @@ def main():
                        "shader_mhz": round(st["shader_mhz"], 1)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_reference_work": round(achieved / VALU_PEAK_TLANEOPS, 4),
                          "achieved_executed": round(achieved_exec, 3), "frac_executed": round(achieved_exec / VALU_PEAK_TLANEOPS, 4),
                          "valu_busy_pmc": valu_busy,
                          "kernel": "ft_trace_kernel_smooth_spheres",
@@ -422,7 +423,7 @@ def main():
                          "algorithmic_flops_per_launch": int(flops_launch),
                          "shader_mhz": round(st["shader_mhz"], 1),
                          "shader_Gcycles_per_launch": round(launch_s * st["shader_mhz"] * 1e6 / 1e9, 4),
-                         "work_note": "achieved / frac price the REFERENCE's work (SURVEY.md section 8d: every SDF evaluation of every ray marched to its end, all "
+                         "work_note": "achieved / frac (= frac_reference_work) price the REFERENCE's work (SURVEY.md section 8d: every SDF evaluation of every ray marched to its end, all "
                                       "children in each; counters of an untimed launch with the escape shortcut off = the oracle's): an algorithmic figure.  "
                                       "achieved_executed / frac_executed price what the kernel executes — it ends rays that can no longer reach the scene's "
                                       "support sphere (sdf_evals_executed_per_frame) and drops, per wave and round, the children whose terms are below half "
