@@ -60,6 +60,7 @@ struct ft_ctx {
     int optTailK = -1;                                     // FT_OPT_TAIL_K: latency mode threshold (-1: per kernel default, 0: off)
     int optChunk = 64;                                     // FT_OPT_CHUNK: jobs per grab (experiments: 64 = one 8x8 tile, 32, 16)
     int optEscape = 1;                                     // FT_OPT_ESCAPE: rays that can no longer reach the scene's support sphere end as misses at once (kernels.hip ft_never_enters)
+    int optLazyUnion = 1;                                  // FT_OPT_LAZY_UNION: a union under an intersect stops at Items.[0] where the intersect's next child decides (kernels.hip)
     int optCull = 1;                                       // FT_OPT_CULL: exact child culling in the lean kernel (kernels.hip); 0 = every child, every round
     int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
@@ -282,6 +283,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.math = libm ? 1u : 0u;
     a.cull = (s->dev.fastPath == 1u && c->optCull) ? 1u : 0u;
     if (!c->optEscape) a.S.escR = -1.0f;
+    a.lazy = c->optLazyUnion ? 1u : 0u;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
     a.materialsExt = s->dMaterialsExt;
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
@@ -333,6 +335,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_TAIL_K: if (value < -1 || value > 64) return setErr(FT_ERR_INVALID, "FT_OPT_TAIL_K: -1 (default), 0 (off) .. 64"); c->optTailK = value; return FT_OK;
     case FT_OPT_CHUNK: if (value != 64 && value != 32 && value != 16) return setErr(FT_ERR_INVALID, "FT_OPT_CHUNK: 64, 32 or 16"); c->optChunk = value; return FT_OK;
     case FT_OPT_ESCAPE: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_ESCAPE: 0 or 1"); c->optEscape = value; return FT_OK;
+    case FT_OPT_LAZY_UNION: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_LAZY_UNION: 0 or 1"); c->optLazyUnion = value; return FT_OK;
     case FT_OPT_CULL: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CULL: 0 or 1"); c->optCull = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_MATH:
@@ -352,6 +355,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
     case FT_OPT_CULL: *value = c->optCull; return FT_OK;
+    case FT_OPT_LAZY_UNION: *value = c->optLazyUnion; return FT_OK;
     case FT_OPT_ESCAPE: *value = c->optEscape; return FT_OK;
     case FT_OPT_CHUNK: *value = c->optChunk; return FT_OK;
     default: return setErr(FT_ERR_INVALID, "unknown option");

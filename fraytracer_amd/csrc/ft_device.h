@@ -117,4 +117,6 @@ struct FtStatsDev {
 #define FT_MAX_SLOTS 48
 #define FT_FLAG_INIT 1u         // FtInstr.flags: accumulator starts at 0 (first child of a smooth union)
 #define FT_FLAG_FAST 2u         // FtInstr.flags: sphere run whose parameters admit the guarded fast path (see scene.cpp)
+#define FT_FLAG_LAZY 4u         // FtInstr.flags of an FT_OP_UNION that is child 0 of an intersect whose child 1 is a primitive: type / data / count = that
+                                // primitive's kind, constant-pool offset and boundary offset (kernels.hip "lazy union")
 #define FT_MAX_STAGE_FLOATS 12288   // <= 48 KB of the constant pool is mirrored in LDS

@@ -43,6 +43,7 @@ struct FtRenderArgs {
     uint32_t ext;             // 1: launch the EXTENSION build of the kernel (set by the host, see capi.cpp)
     uint32_t maxBounces;      // EXTENSION glass: interactions per path; 0 = glass shades as a solid
     uint32_t spectral;        // EXTENSION: wavelength bins (0 = off)
+    uint32_t lazy;            // 1: unions under an intersect stop at Items.[0] where the intersect's next child already decides (FT_OPT_LAZY_UNION; kernels.hip)
     uint32_t refillMin;       // idle lanes a wave waits for before it takes new rays (1 = refill at once; kernels.hip "Burst refill")
     uint32_t math;            // 0: the default kernels; 1: launch the *_libm build (FT_OPT_MATH = glibc and the scene has a unionSmooth)
     uint32_t shrink1, shrink2;   // guided hand-out: from job shrink1 on a wave takes chunk / 2 jobs at a time, from shrink2 on chunk / 4 (nJobs: never)

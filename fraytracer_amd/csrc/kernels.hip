@@ -419,10 +419,14 @@ __device__ __forceinline__ uint32_t ft_dbg_now() { unsigned long long t; asm vol
 #define FT_UDBG_T1(k, v) do {} while (0)
 #endif
 
+// cap / capBound ("lazy union", FT_FLAG_LAZY): the union is child 0 of an intersect whose child 1 evaluates to `cap` at p, with pruning bound
+// `capBound` (SdfForm.fs:60-63: max = u; if max < bound then max = Max(max, cap)).  The fold below starts at Items.[0] and only falls, so once
+// Items.[0]'s distance is <= cap (and < capBound) the intersect's result is `cap` whatever the rest of the walk would find: the lane stops there.
+// (The material of an evaluation is only asked for at a hit, and the caller sets cap only where cap >= the ray's epsilon, i.e. no hit; -inf = off.)
 template <bool FQ>
 __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            const float* __restrict__ sd, const uint32_t* __restrict__ sl,
-                                           float& outD, uint32_t& outLeaf) {   // unions without FT_PR_CALL children
+                                           float& outD, uint32_t& outLeaf, float cap, float capBound) {   // unions without FT_PR_CALL children
     FT_UDBG_T0(tWalk);
     const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
     const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
@@ -496,7 +500,7 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
         if (type == FT_PR_SLOT) { d = sd[data * FT_BLOCK]; l = sl[data * FT_BLOCK]; }
         else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p); l = mat; }
         FT_UDBG_T1(9, tPrim);
-        if (first) { mn = d; leaf = l; first = false; }
+        if (first) { mn = d; leaf = l; first = false; if (mn <= cap && mn < capBound) break; }   // lazy union: the rest cannot matter
         else {
             if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
             mn = ft_min(mn, d);                                        // SdfForm.fs:33
@@ -510,12 +514,12 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
 template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
-                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk);
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, float epsHit = __builtin_inff());
 
 template <bool FQ, int MATH>
 __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
                                            float* __restrict__ sd, uint32_t* __restrict__ sl, const float* __restrict__ ldsC,
-                                           bool fastOk, bool nearOk, float& outD, uint32_t& outLeaf) {
+                                           bool fastOk, bool nearOk, float& outD, uint32_t& outLeaf, float cap, float capBound) {
     const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
     const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
     const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
@@ -566,7 +570,7 @@ __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_
             }
         }
         else { d = prim_eval_t<FQ>(type, pool_at(consts, data), p); l = cur.b.z; }
-        if (first) { mn = d; leaf = l; first = false; }
+        if (first) { mn = d; leaf = l; first = false; if (mn <= cap && mn < capBound) break; }   // lazy union (see eval_union_prims)
         else {
             if (d < mn) leaf = l;                                      // SdfObject.fs:41-43
             mn = ft_min(mn, d);                                        // SdfForm.fs:33
@@ -652,7 +656,7 @@ __device__ __forceinline__ void eval_union_coop(const FtSceneDev& S, const FtGri
 
 template <bool WITH_UNION, bool CALLS, int MATH, bool COOP>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
-                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk) {
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, float epsHit) {
     cfp consts = as_const(S.consts);
     for (; pc < pcEnd; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
@@ -714,12 +718,24 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
                     if (fastOk && S.fastQ) eval_union_coop<true, CALLS, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                     else eval_union_coop<false, CALLS, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
                 } else
+                {
+                    // Lazy union (FT_FLAG_LAZY, set by the flattener where this union is child 0 of an intersect whose child 1 is a primitive): that
+                    // child's value and pruning bound at p, computed exactly as the FT_OP_ISECT_RUN behind this instruction will compute them.
+                    // Only where it is >= the ray's epsilon — the intersect, and everything above it, then cannot produce a hit through this
+                    // object, so the material the shortened walk reports is never asked for (epsHit = +inf: callers that want the material everywhere).
+                    float cap = -__builtin_inff(), capBound = 0.0f;
+                    if (in.flags & FT_FLAG_LAZY) {
+                        const float d1 = prim_eval(in.type, consts + in.data, p);
+                        cfp bd = consts + in.count;
+                        if (d1 >= epsHit) { cap = d1; capBound = ft_distance(ld3(bd), p) + bd[3]; }
+                    }
                 if constexpr (CALLS) {                                 // scenes with sub-program children (FtSceneDev.fastPath == 2)
-                    if (fastOk && S.fastQ) eval_union<true, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
-                    else eval_union<false, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l);
+                    if (fastOk && S.fastQ) eval_union<true, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l, cap, capBound);
+                    else eval_union<false, MATH>(S, as_const(S.grids)[in.aux], p, sd, sl, ldsC, fastOk, nearOk, d, l, cap, capBound);
                 } else {
-                    if (fastOk && S.fastQ) eval_union_prims<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
-                    else eval_union_prims<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l);
+                    if (fastOk && S.fastQ) eval_union_prims<true>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l, cap, capBound);
+                    else eval_union_prims<false>(S, as_const(S.grids)[in.aux], p, sd, sl, d, l, cap, capBound);
+                }
                 }
                 *dst = d; sl[in.dst * FT_BLOCK] = l;
             }
@@ -732,10 +748,10 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
 
 template <bool CALLS, int MATH>
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
-                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf) {
+                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf, float epsHit = __builtin_inff()) {
     const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
     const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk);
+    ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk, epsHit);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -1376,7 +1392,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             else {
                 const f3 q = query_point();
                 if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf, coopRow, cullN);
-                else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf);
+                else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf,          // lazy unions: off (+inf) inside a glass body, whose exit is a "hit" at large values
+                                                  (EXT && s.sign < 0.0f) || a.lazy == 0u ? __builtin_inff() : s.eps);
             }
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
             if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance

@@ -456,6 +456,8 @@ struct Flattener {
     bool emitIntersect(const std::vector<int>& kids, uint32_t dst, int firstObject) {
         if (firstObject >= 0) { if (!emitObject(firstObject, dst)) return false; }
         else if (!emitForm(kids[0], dst)) return false;
+        // child 0 is a grid union evaluated straight into dst (its FT_OP_UNION is the instruction just emitted): see "lazy union" below
+        const size_t unionAt = (!out.instr.empty() && out.instr.back().op == FT_OP_UNION && out.instr.back().dst == dst) ? out.instr.size() - 1 : (size_t)-1;
         for (size_t k = 1; k < kids.size();) {
             const size_t run = runLength(kids, k);
             if (run > 0) {
@@ -465,6 +467,13 @@ struct Flattener {
                 for (size_t j = 0; j < run; ++j) addConsts(b.forms[kids[k + j]].params);
                 i.aux = (uint32_t)out.consts.size();
                 for (size_t j = 0; j < run; ++j) addBoundary(b.forms[kids[k + j]].boundary);
+                if (k == 1 && unionAt != (size_t)-1 && unionAt + 1 == out.instr.size()) {
+                    // Lazy union: the intersect's value is Max(u, d1) once u < child 1's pruning bound (SdfForm.fs:60-63), and the union's fold starts at
+                    // Items.[0] and only falls — wherever Items.[0] is already <= d1 the rest of the walk cannot change the result.  The kernel
+                    // (FT_OP_UNION, FT_FLAG_LAZY) recomputes d1 and the bound from these offsets with the expressions FT_OP_ISECT_RUN uses.
+                    FtInstr& u = out.instr[unionAt];
+                    u.flags |= FT_FLAG_LAZY; u.type = i.type; u.data = i.data; u.count = i.aux;
+                }
                 out.instr.push_back(i);
                 k += run;
             } else {

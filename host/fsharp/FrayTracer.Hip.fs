@@ -110,11 +110,12 @@ module Native =
     /// on the GPU — what MathF.Exp / Log / Pow return under .NET on Linux x64, i.e. the CPU path of this very process
     let setMath (mode : int) = if ft_ctx_set_option (ctx.Value, 6, mode) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))
 
-    /// FT_OPT_CULL (9) and FT_OPT_ESCAPE (10), both on by default: the smooth-union kernel skips children whose terms cannot change the running
-    /// float32 sum, and a ray that can no longer come within epsilon of the scene's support sphere ends as a miss at once.  Both are exact — the
-    /// frame and the ray / hit counters do not change — and only lower Stats.SdfEvals; `false` makes the GPU do every evaluation the CPU path does.
+    /// FT_OPT_CULL (9), FT_OPT_ESCAPE (10), FT_OPT_LAZY_UNION (11), all on by default: the smooth-union kernel skips children whose terms cannot change
+    /// the running float32 sum, a ray that can no longer come within epsilon of the scene's support sphere ends as a miss at once, and a union under
+    /// an intersect stops at Items.[0] where the intersect's next child already decides.  All are exact — the frame and the ray / hit counters do
+    /// not change; `false` makes the GPU do every evaluation, child and candidate the CPU path does.
     let setExactShortcuts (on : bool) =
-        for opt in [ 9; 10 ] do
+        for opt in [ 9; 10; 11 ] do
             if ft_ctx_set_option (ctx.Value, opt, (if on then 1 else 0)) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))
 
     let check (h : int) =

@@ -122,6 +122,9 @@ typedef enum ft_option {
     FT_OPT_ESCAPE = 10,           /* 1 (default): a ray that can no longer come within epsilon of the scene's support sphere — outside it and heading away, or
                                    * passing it by — ends as the miss its march is bound to end in, without further evaluations (same frame, fewer sdf_evals);
                                    * 0: every ray marches until its Length is used up, as the reference does */
+    FT_OPT_LAZY_UNION = 11,       /* 1 (default): SdfForm.union as the first child of an intersect (the reference's own scene: intersect(union of tori, sphere))
+                                   * stops its candidate walk at Items.[0] wherever that distance is already <= the next child's, which then decides the
+                                   * intersect's value (exact; only where no hit is possible); 0: every union walk runs to its end */
     FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's

@@ -423,6 +423,51 @@ def test_escape_shortcut_changes_no_pixel(gpu, oracle):
         gpu.set_option("escape", 1)
 
 
+def test_lazy_union_under_intersect_changes_no_pixel(gpu, oracle):
+    """FT_OPT_LAZY_UNION: a union that is child 0 of an intersect stops its walk at Items.[0] wherever that distance is already <= the next
+    child's (which then decides the intersect).  Frames, counters, explicit rays and the materials SdfObject.tryTrace reports are the
+    oracle's with the option on and off — for the reference's own structure, for a non-sphere second child, for a union whose objects carry
+    different materials (the material of a shortened walk must never be asked for), under subtract and inside another union."""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    cam = syn.default_camera()
+    P = SdfForm.Primitive
+    rng = syn.Rng(5)
+    mats = [SdfMaterial.createSolid((0.2 + 0.1 * i, 0.9 - 0.1 * i, 0.5)) for i in range(6)]
+    blobs = [SdfObject.create(mats[i % 6], P.sphere(rng.pointInBall(3.0), rng.range(0.3, 0.9))) for i in range(40)]
+    tori = [SdfObject.create(mats[i % 6], P.torus(rng.pointInBall(3.0), rng.pointOnSphere(1.0), rng.range(0.4, 0.8), rng.range(0.1, 0.25))) for i in range(30)]
+    clipped = SdfObject.intersect(SdfObject.union(blobs), [P.sphere((0.2, 0.1, 0.0), 2.2)])
+    by_torus = SdfObject.intersect(SdfObject.union(tori), [P.torus((0, 0, 0), (0, 1, 0), 2.0, 1.2), P.sphere((0, 0, 0), 3.0)])
+    carved = SdfObject.subtract(SdfObject.intersect(SdfObject.union(blobs[:20] + tori[:10]), [P.sphere((0, 0, 0), 2.5)]), P.sphere((-0.5, 1.0, -2.0), 1.5))
+    nested = SdfObject.union([SdfObject.intersect(SdfObject.union(blobs[:12]), [P.sphere((-1.5, 0, 0), 1.6)]),
+                              SdfObject.intersect(SdfObject.union(tori[:12]), [P.capsule((1.0, -1.0, 0), (2.0, 1.0, 0.5), 1.4)]),
+                              SdfObject.create(mats[0], P.sphere((0, -2.5, 0), 0.6))])
+    cases = [("Program.fs structure", syn.console_scene(n=150, size=200)[0]), ("clipped blobs", SdfScene(clipped, syn.BACKGROUND, syn.program_lights())),
+             ("torus as second child", SdfScene(by_torus, syn.BACKGROUND, syn.program_lights())), ("carved", SdfScene(carved, syn.BACKGROUND, syn.program_lights())),
+             ("intersects inside a union", SdfScene(nested, syn.BACKGROUND, syn.program_lights()))]
+    try:
+        for name, scene in cases:
+            ds, os_ = both(gpu, oracle, scene)
+            W, H = 200, 136
+            want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array())
+            rr = np.random.default_rng(3)
+            o = (rr.normal(size=(500, 3)) * 3.0).astype(np.float32)
+            d = rr.normal(size=(500, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+            rays = np.concatenate([o, d, np.full((500, 1), 30, np.float32), rr.choice([0.01, 0.3, 1.5], (500, 1)).astype(np.float32)], axis=1).astype(np.float32)
+            want_obj = os_.object_try_trace(rays)
+            want_obj = want_obj[0] if isinstance(want_obj, tuple) else want_obj
+            for lazy in (1, 0):
+                gpu.set_option("lazy_union", lazy)
+                g, gst = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+                assert_bit_equal(g, want, f"{name}, lazy_union {lazy}")
+                check_counts(gst, ocnt)
+                got_obj = ds.object_try_trace(rays)
+                assert_bit_equal(got_obj[0] if isinstance(got_obj, tuple) else got_obj, want_obj, f"{name}: SdfObject.tryTrace (materials), lazy_union {lazy}")
+                with np.errstate(all="ignore"):
+                    assert_bit_equal(ds.trace_rays(rays)[0], os_.trace_rays(rays)[0], f"{name}: ray buffer, lazy_union {lazy}")
+    finally:
+        gpu.set_option("lazy_union", 1)
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
