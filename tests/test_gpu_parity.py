@@ -441,7 +441,11 @@ def test_lazy_union_under_intersect_changes_no_pixel(gpu, oracle):
     nested = SdfObject.union([SdfObject.intersect(SdfObject.union(blobs[:12]), [P.sphere((-1.5, 0, 0), 1.6)]),
                               SdfObject.intersect(SdfObject.union(tori[:12]), [P.capsule((1.0, -1.0, 0), (2.0, 1.0, 0.5), 1.4)]),
                               SdfObject.create(mats[0], P.sphere((0, -2.5, 0), 0.6))])
+    holed = SdfObject.subtract(SdfObject.union(blobs[:25]), P.sphere((0.3, 0.2, -1.0), 1.8))                  # a union directly under subtract
+    form_level = SdfObject.create(mats[2], SdfForm.subtract(SdfForm.intersect([SdfForm.union([P.sphere(rng.pointInBall(2.5), rng.range(0.3, 0.7)) for _ in range(30)]),
+                                                                                   P.sphere((0, 0, 0), 2.0)]), P.capsule((-1, -1, -2), (1, 1, -2), 1.0)))
     cases = [("Program.fs structure", syn.console_scene(n=150, size=200)[0]), ("clipped blobs", SdfScene(clipped, syn.BACKGROUND, syn.program_lights())),
+             ("union under subtract", SdfScene(holed, syn.BACKGROUND, syn.program_lights())), ("form-level subtract(intersect(union, sphere), capsule)", SdfScene(form_level, syn.BACKGROUND, syn.program_lights())),
              ("torus as second child", SdfScene(by_torus, syn.BACKGROUND, syn.program_lights())), ("carved", SdfScene(carved, syn.BACKGROUND, syn.program_lights())),
              ("intersects inside a union", SdfScene(nested, syn.BACKGROUND, syn.program_lights()))]
     try:
