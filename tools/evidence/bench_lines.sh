@@ -1,3 +1,5 @@
+# One gpurun call of the round-end evidence: the bench line, every scene and extension, the tail probe, the RCCL rehearsal and the whole-frame checks.
+# Run after the profile summaries of the same build are in profiles/ (bench.py quotes PMC figures only from a summary with the running build's stamp).
 set -u
 mkdir -p gpurun_out/ev6
 timeout -k 10 400 python bench.py > gpurun_out/ev6/bench.json 2> gpurun_out/ev6/bench.err; echo bench rc=$?
