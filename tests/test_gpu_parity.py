@@ -472,6 +472,35 @@ def test_lazy_union_under_intersect_changes_no_pixel(gpu, oracle):
         gpu.set_option("lazy_union", 1)
 
 
+def test_culling_on_random_smooth_unions(gpu, oracle):
+    """a short run of tools/fuzz_cull.py inside the suite: random smooth unions of spheres (counts, strengths, radii, extents over two decades) seen by
+    random cameras, from inside the cloud to far outside, on wide low frames where the culling pass drops children — float for float against the oracle"""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene, SdfLight, Camera, Lens
+    dropped = 0
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(32, 301))
+        spread = float(10.0 ** rng.uniform(-0.5, 1.0))
+        strength = float(10.0 ** rng.uniform(-1.5, 0.18))
+        rmax = float(spread * 10.0 ** rng.uniform(-1.5, -0.5))
+        c = rng.normal(size=(n, 3)) * spread * 0.5
+        forms = [SdfForm.Primitive.sphere(tuple(float(v) for v in c[i]), float(rng.uniform(0.2, 1.0) * rmax)) for i in range(n)]
+        lights = [SdfLight.directional(tuple(float(v) for v in rng.normal(size=3)), (0.5, 0.5, 0.5))]
+        scene = SdfScene(SdfObject.create(SdfMaterial.createSolid((0.9, 0.6, 0.3)), SdfForm.unionSmooth(strength, forms)), syn.BACKGROUND, lights)
+        pos = rng.normal(size=3); pos = pos / np.linalg.norm(pos) * spread * float(10.0 ** rng.uniform(-0.7, 0.8))
+        cam = Camera.lookAt(Position=tuple(float(v) for v in pos), LookAt=tuple(float(v) for v in rng.normal(size=3) * spread * 0.2), Up=(0.0, 1.0, 0.0),
+                            Lens=Lens.create(float(rng.uniform(20.0, 90.0))))
+        W, H = int(rng.choice([1024, 2048])), 8
+        eps, length = float(10.0 ** rng.uniform(-3.0, -1.5)), float(spread * rng.uniform(2.0, 40.0))
+        ds, os_ = both(gpu, oracle, scene)
+        g, gst = ds.render(eps, length, ft.ImageSize(W, H), cam)
+        o, ocnt = os_.render(eps, length, W, H, cam.as_array())
+        assert_bit_equal(g, o, f"culling fuzz seed {1000 + seed}: {n} spheres, strength {strength:.3g}, extent {spread:.3g}")
+        check_counts(gst, ocnt)
+        dropped += gst["culled_fraction"] > 0.1
+    assert dropped >= 5, dropped                                       # the pass really ran on a fair share of them
+
+
 def test_c1_single_sphere(gpu, oracle):
     scene, size = syn.config1()
     g, gst, o, ocnt = render_both(gpu, oracle, scene, size.X, size.Y)
