@@ -799,10 +799,28 @@ __device__ __forceinline__ f3 ft_readlane3(f3 v, int l) {
     return mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), l)),
                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), l)));
 }
-__device__ __forceinline__ float ft_wave_max_all(float v) {            // all 64 lanes execute; every lane gets the maximum
-    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+// Wave-wide maximum and prefix sum for the pass, from DPP row shifts and v_readlane: no LDS traffic, no dependent round trips (the first version
+// used ds_bpermute shuffles: 40 dependent LDS round trips per round — the pass cost 3.7 ms of a 34 ms frame).  All 64 lanes must execute.
+// Checked against the host in tools/experiments/dpp_scan.hip.
+template <int CTRL> __device__ __forceinline__ float ft_dpp(float old, float v) {      // lanes without a source lane keep `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ft_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float ft_wave_max_all(float v) {            // v >= 0 in every lane; wave-uniform result
+    v = __builtin_fmaxf(v, ft_dpp<0x111>(0.0f, v)); v = __builtin_fmaxf(v, ft_dpp<0x112>(0.0f, v));     // row_shr:1, 2, 4, 8: lane 15 of every row of 16 holds the row's maximum
+    v = __builtin_fmaxf(v, ft_dpp<0x114>(0.0f, v)); v = __builtin_fmaxf(v, ft_dpp<0x118>(0.0f, v));
+    return __builtin_fmaxf(__builtin_fmaxf(ft_readlane_f(v, 15), ft_readlane_f(v, 31)), __builtin_fmaxf(ft_readlane_f(v, 47), ft_readlane_f(v, 63)));
+}
+__device__ __forceinline__ float ft_wave_scan_incl(float v, float& total) {            // inclusive prefix sum in lane order; total = lane 63's (wave-uniform)
+    const uint32_t lane = threadIdx.x & 63u;
+    v += ft_dpp<0x111>(0.0f, v); v += ft_dpp<0x112>(0.0f, v); v += ft_dpp<0x114>(0.0f, v); v += ft_dpp<0x118>(0.0f, v);   // inclusive within each row of 16
+    const float r0 = ft_readlane_f(v, 15), r1 = ft_readlane_f(v, 31), r2 = ft_readlane_f(v, 47), r3 = ft_readlane_f(v, 63);
+    const float p2 = r0 + r1, p3 = p2 + r2;
+    v += lane >= 48u ? p3 : (lane >= 32u ? p2 : (lane >= 16u ? r0 : 0.0f));
+    total = p3 + r3;
     return v;
 }
+__device__ __forceinline__ float ft_wave_shift_right1(float v) { return ft_dpp<0x138>(0.0f, v); }   // wave_shr:1; lane 0 gets 0
 // -> survivors among the first min(count, FT_CULL_MAX) children of instruction 0, their records in row[0 ..), or FT_CULL_NONE (row untouched).
 // active / am: lanes that evaluate p this round (am = __ballot(active) != 0).  Wave-uniform result; executed by all 64 lanes.
 __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const f3 p, bool active, unsigned long long am,
@@ -841,9 +859,9 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
         const float slack = 0.01f + rho;                               // 0.01 >> every rounding here and in the lanes' own distances
         const float dlo = dc - slack, dhi = dc + slack;
         const float low = have ? __builtin_amdgcn_exp2f(__builtin_fmaxf(si * dhi * 1.44269504f - 0.02f, -200.0f)) : 0.0f;
-        float incl = low;                                              // inclusive prefix sum over the lanes = over the children in list order
-        for (int off = 1; off < 64; off <<= 1) { const float v = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += v; }
-        float excl = __shfl_up(incl, 1, 64); if (lane == 0u) excl = 0.0f;
+        float passTotal;
+        const float incl = ft_wave_scan_incl(low, passTotal);          // inclusive prefix sum over the lanes = over the children in list order
+        const float excl = ft_wave_shift_right1(incl);
         const float slow = (carry + excl) * 0.99609375f;              // 1 - 2^-8
         const uint32_t sbits = __float_as_uint(slow);
         const float x = __builtin_fminf(__builtin_fmaxf(si * dlo * 1.44269504f, -1000.0f), 1000.0f);   // log2 of the largest term any lane can compute ...
@@ -853,7 +871,7 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
         const unsigned long long km = __ballot(keep);
         if (keep) dst[kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = prm;
         kept += (uint32_t)__popcll(km);
-        carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+        carry += passTotal;
     }
     return kept;
 }
