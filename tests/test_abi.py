@@ -75,8 +75,13 @@ def test_the_library_reads_no_environment_variables():
         assert [host.get_option(k) for k in ("math", "tail_k", "guided", "chunk")] == [0, -1, 0, 64]
         host.set_option("math", 2); host.set_option("tail_k", 8); host.set_option("guided", 1); host.set_option("chunk", 16)
         assert [host.get_option(k) for k in ("math", "tail_k", "guided", "chunk")] == [2, 8, 1, 16]
+        # the three exact shortcuts are on unless switched off
+        assert [host.get_option(k) for k in ("cull", "escape", "lazy_union")] == [1, 1, 1]
+        for k in ("cull", "escape", "lazy_union"):
+            host.set_option(k, 0); assert host.get_option(k) == 0
+            host.set_option(k, 1)
         for name, bad in (("refill_min", 0), ("refill_min", 65), ("host_chunks", 17), ("host_pin", 2), ("max_blocks_per_cu", -1),
-                          ("math", 3), ("tail_k", 65), ("tail_k", -2), ("guided", 2), ("chunk", 48)):
+                          ("math", 3), ("tail_k", 65), ("tail_k", -2), ("guided", 2), ("chunk", 48), ("cull", 2), ("escape", -1), ("lazy_union", 2)):
             try:
                 host.set_option(name, bad)
             except ft.FrayTracerError as e:
