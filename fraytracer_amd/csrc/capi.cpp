@@ -62,6 +62,7 @@ struct ft_ctx {
     int optEscape = 1;                                     // FT_OPT_ESCAPE: rays that can no longer reach the scene's support sphere end as misses at once (kernels.hip ft_never_enters)
     int optLazyUnion = 1;                                  // FT_OPT_LAZY_UNION: a union under an intersect stops at Items.[0] where the intersect's next child decides (kernels.hip)
     int optCull = 1;                                       // FT_OPT_CULL: exact child culling in the lean kernel (kernels.hip); 0 = every child, every round
+    int optCarved = 1;                                     // FT_OPT_CARVED: scenes of the "carved union" shape take their specialised kernel (kernels.hip ft_eval_carved); 0 = the general interpreter
     int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
 
@@ -71,6 +72,7 @@ struct ft_scene {
     void* dBlob = nullptr;
     FtSceneDev dev{};
     const float* dMaterialsExt = nullptr;    // EXTENSION table, handed to the kernel through FtRenderArgs
+    FtCarve carve{};                         // fastPath == 3: tail + device pointers of the terminated candidate lists
     bool usesExpLog = false;                 // the program has a unionSmooth (SdfForm.fs:80,82): the only place FT_OPT_MATH matters while tracing
 };
 
@@ -164,7 +166,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     const size_t oInstr = placed(cur, f.instr), oConsts = placed(cur, f.consts), oGrids = placed(cur, f.grids),
                  oKids = placed(cur, f.children), oCtr = placed(cur, f.cellCenters), oStart = placed(cur, f.cellStart),
                  oItems = placed(cur, f.items), oLights = placed(cur, f.lights), oMats = placed(cur, f.materials),
-                 oMatX = placed(cur, f.materialsExt);
+                 oMatX = placed(cur, f.materialsExt), oItemsT = placed(cur, f.itemsT), oStartT = placed(cur, f.cellStartT);
     std::vector<unsigned char> host(cur, 0);
     auto put = [&](size_t at, const void* p, size_t n) { if (n) memcpy(host.data() + at, p, n); };
     put(oInstr, f.instr.data(), f.instr.size() * sizeof(FtInstr));
@@ -177,6 +179,8 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     put(oLights, f.lights.data(), f.lights.size() * sizeof(FtLight));
     put(oMats, f.materials.data(), f.materials.size() * 4);
     put(oMatX, f.materialsExt.data(), f.materialsExt.size() * 4);
+    put(oItemsT, f.itemsT.data(), f.itemsT.size() * sizeof(FtItemRec));
+    put(oStartT, f.cellStartT.data(), f.cellStartT.size() * 4);
     FtSceneDev& d = s->dev;
     d = FtSceneDev{};
     d.nInstr = f.nMainInstr; d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
@@ -198,6 +202,9 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d.lights = reinterpret_cast<const FtLight*>(b + oLights);
     d.materials = reinterpret_cast<const float*>(b + oMats);
     s->dMaterialsExt = reinterpret_cast<const float*>(b + oMatX);
+    s->carve = f.carve;
+    s->carve.itemsT = reinterpret_cast<const FtItemRec*>(b + oItemsT);
+    s->carve.cellStartT = reinterpret_cast<const uint32_t*>(b + oStartT);
     return FT_OK;
 }
 
@@ -208,8 +215,9 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 #define FT_COOP_SEG_FLOATS FT_CULL_ROW        // the wave's row of culled children's records (ft_kernels.h); its first 256 floats serve the latency mode
 // traceLaunch: the lean trace kernel keeps its accumulator in a register and is launched with nSlots = 0 (launchTrace) — 2 KB per workgroup
 // that decide between 6 and 7 resident workgroups per CU; every other user of a lean scene (ft_eval_distance) runs the general interpreter
-size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false) {
-    const size_t nSlots = (traceLaunch && s->dev.fastPath == 1u) ? 0 : s->dev.nSlots;
+// variant: the kernel family of a trace launch (launchTrace: FtSceneDev.fastPath, or 0 where a carved scene takes the general kernel)
+size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false, unsigned variant = 0) {
+    const size_t nSlots = (traceLaunch && (variant == 1u || variant == 3u)) ? 0 : s->dev.nSlots;       // the lean and the carved kernels keep their values in registers
     size_t floats = (size_t)FT_LDS_HDR_FLOATS + nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
     if (libm) floats = ((floats + 1) & ~(size_t)1) + (size_t)FT_LIBM_TAB_DOUBLES * 2;
     if (s->dev.fastPath == 1u) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
@@ -251,10 +259,29 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     uint32_t* counter = c->dCounter + (lane ? 16 : 0);
     int perCU = 0;
     const bool libm = libmLaunch(c, s);
-    const size_t lds = ldsBytes(s, libm, true);
-    HIP_TRY(ft_trace_occupancy(s->dev.fastPath, a.ext != 0u, libm, lds, &perCU));
-    perCU = std::max(1, std::min(perCU, 8));
-    if (c->optMaxBlocksPerCU > 0) perCU = std::min(perCU, c->optMaxBlocksPerCU);       // FT_OPT_MAX_BLOCKS_PER_CU (experiments only)
+    // kernel family: a "carved union" scene takes the general kernels for EXTENSION launches and with FT_OPT_CARVED = 0
+    const unsigned variant = (s->dev.fastPath == 3u && (a.ext != 0u || !c->optCarved)) ? 0u : s->dev.fastPath;
+    const size_t lds = ldsBytes(s, libm, true, variant);
+    {   // a scene too large for the workgroup's LDS is refused here, not by a launch failure
+        int maxLds = 0;
+        HIP_TRY(hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));
+        if (lds > (size_t)maxLds) return setErr(FT_ERR_UNSUPPORTED, "scene needs " + std::to_string(lds) + " bytes of LDS per workgroup; the device offers " + std::to_string(maxLds));
+    }
+    HIP_TRY(ft_trace_occupancy(variant, s->carve.kind, a.ext != 0u, libm, lds, &perCU));
+    if (perCU < 1) return setErr(FT_ERR_UNSUPPORTED, "the trace kernel does not fit a compute unit with this scene's LDS footprint");
+    perCU = std::min(perCU, 8);
+    if (c->optMaxBlocksPerCU > 0) perCU = std::min(perCU, c->optMaxBlocksPerCU);       // FT_OPT_MAX_BLOCKS_PER_CU (experiments)
+    else if (variant != 1u) {
+        // Small frames: the job queue can only even out the load while there are several tiles per resident wave, and the grid-union kernels lose little
+        // throughput at half their occupancy (the 4000^2 Program.fs frame: 5.4 ms at 7 workgroups per CU, 6.0 at 4).  With about as many tiles as waves
+        // every tile is handed out at once, the heavy ones sit several deep on some SIMDs while others idle, and the frame lasts as long as the
+        // slowest of them at full contention.  So: about one resident wave per four tiles, at least two workgroups per CU (measured per size,
+        // profiles/r04_blocks_by_frame_size.jsonl: the reference's own 1000^2 frame 1.45 -> 1.27 ms, C2 at 1024^2 0.90 -> 0.61 ms).
+        const uint64_t tiles = ((uint64_t)a.nJobs + (uint64_t)c->optChunk - 1) / (uint64_t)c->optChunk;
+        const uint64_t wavesPerLayer = (uint64_t)c->numCUs * (FT_BLOCK / 64);
+        const uint64_t want = (tiles + 2 * wavesPerLayer) / (4 * wavesPerLayer);              // round(tiles / (4 x waves of one workgroup per CU))
+        perCU = (int)std::min<uint64_t>((uint64_t)perCU, std::max<uint64_t>(2, want));
+    }
     const uint64_t maxBlocks = (uint64_t)c->numCUs * perCU;
     const uint64_t wantBlocks = ((uint64_t)a.nJobs + FT_BLOCK - 1) / FT_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min(maxBlocks, wantBlocks));
@@ -279,7 +306,9 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.counter = counter;
     a.stats = c->dStats;
     a.S = s->dev;
-    if (s->dev.fastPath == 1u) a.S.nSlots = 0;             // the lean kernel uses no value slots: its LDS layout has none (ldsBytes)
+    a.S.fastPath = variant;
+    a.carve = s->carve;
+    if (variant == 1u || variant == 3u) a.S.nSlots = 0;    // the lean and carved kernels use no value slots: their LDS layout has none (ldsBytes)
     a.math = libm ? 1u : 0u;
     a.cull = (s->dev.fastPath == 1u && c->optCull) ? 1u : 0u;
     if (!c->optEscape) a.S.escR = -1.0f;
@@ -338,6 +367,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_LAZY_UNION: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_LAZY_UNION: 0 or 1"); c->optLazyUnion = value; return FT_OK;
     case FT_OPT_CULL: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CULL: 0 or 1"); c->optCull = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
+    case FT_OPT_CARVED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CARVED: 0 or 1"); c->optCarved = value; return FT_OK;
     case FT_OPT_MATH:
         if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
         c->optMath = value; return FT_OK;
@@ -354,6 +384,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_MATH: *value = c->optMath; return FT_OK;
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
+    case FT_OPT_CARVED: *value = c->optCarved; return FT_OK;
     case FT_OPT_CULL: *value = c->optCull; return FT_OK;
     case FT_OPT_LAZY_UNION: *value = c->optLazyUnion; return FT_OK;
     case FT_OPT_ESCAPE: *value = c->optEscape; return FT_OK;
@@ -861,7 +892,7 @@ int ft_eval_distance(ft_ctx* c, const ft_scene* s, const ft_vec3* pts, int64_t n
 
 int ft_math_eval(ft_ctx* c, int32_t op, const float* x, const float* y, int64_t n, float* out) {
     int rc = requireDevice(c); if (rc) return rc;
-    if (!x || !out || n < 0 || op < 0 || op > 12 || ((op == 3 || op >= 10) && !y)) return setErr(FT_ERR_INVALID, "bad argument");
+    if (!x || !out || n < 0 || op < 0 || op > 14 || ((op == 3 || op >= 10) && !y)) return setErr(FT_ERR_INVALID, "bad argument");
     if (n == 0) return FT_OK;
     const size_t b = align256((size_t)n * 4);
     if ((rc = ensureScratch(c, 3 * b))) return rc;

@@ -105,6 +105,23 @@ struct FtSceneDev {             // passed by value as kernel argument
                                 // (read by the *_libm kernels only)
 };
 
+// "Carved union" kernels (FtSceneDev.fastPath == 3; kernels.hip ft_eval_carved): the whole program is ONE grid union of plain primitives
+// followed by at most FT_CARVE_TAIL intersect / subtract steps with one primitive each — the shape of the reference's own scene,
+// subtract(intersect(union [1000 tori], [sphere]), sphere) (Program.fs:67-77).  The flattener records the tail here and lays the union's
+// candidate lists out a second time with a terminator behind every cell's list (LowerBound = +inf: the reference's test :30 fails on it
+// for every running minimum, NaN included), so that the walk needs neither an end index nor a bounds check; cellStartT[cell] is the BYTE
+// offset of the cell's first record in itemsT.
+#define FT_CARVE_TAIL 2
+#define FT_CARVE_MIXED 7u       // FtCarve.kind when the union's children are not all of one primitive kind
+struct FtCarveOp { uint32_t op, type, data, bound; };   // op: FT_OP_ISECT_RUN (one child: consts[data], boundary consts[bound]) or FT_OP_SUBTRACT (consts[data])
+struct FtCarve {
+    uint32_t kind;              // FtPrim of every child of the union, or FT_CARVE_MIXED
+    uint32_t nTail;
+    FtCarveOp tail[FT_CARVE_TAIL];
+    const FtItemRec* itemsT;    // per cell: its candidates in list order, then one terminator record; one spare record at the very end
+    const uint32_t* cellStartT; // per cell: byte offset into itemsT
+};
+
 struct FtStatsDev {
     unsigned long long rays_primary, rays_shadow, rays_ext, hits_primary, hits_shadow, sdf_evals, flags, wave_evals;
     unsigned long long coop_evals;            // evaluations done in latency mode (one ray per wave)

@@ -51,6 +51,7 @@ struct FtRenderArgs {
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move
     float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)
+    FtCarve carve;            // FtSceneDev.fastPath == 3: the union's tail and its terminated candidate lists (ft_device.h "Carved union")
 };
 
 #ifdef __cplusplus
@@ -83,7 +84,7 @@ hipError_t ft_launch_tonemap(const float* frame, uint32_t X, uint32_t Y, uint32_
 // ft_render_multi: gathered slabs [rank][stripe][...] -> frame [stripe][rank][...] on the device
 hipError_t ft_launch_deinterleave(const float* recv, float* frame, unsigned long long stripeFloats, uint32_t nStripes, uint32_t nRanks, hipStream_t st);
 hipError_t ft_launch_selftest(int op, uint32_t lo, uint32_t hi, unsigned long long* d_mismatches, hipStream_t st);
-hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU);
+hipError_t ft_trace_occupancy(unsigned fastPath, unsigned carveKind, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU);
 #ifdef __cplusplus
 }
 #endif

@@ -1037,6 +1037,131 @@ __device__ __forceinline__ void ft_eval_smooth_spheres_packed(const FtSceneDev& 
 }
 
 // ------------------------------------------------------------------------------------------------
+// "Carved union" evaluator (FtSceneDev.fastPath == 3; ft_device.h FtCarve; round 4).
+//
+// The reference's own workload is subtract(intersect(union [1000 tori], [sphere]), sphere) (Program.fs:67-77).  For programs of that shape —
+// ONE grid union of plain primitives, then at most FT_CARVE_TAIL single-primitive intersect / subtract steps — the interpreter is replaced
+// by straight-line code: the union's running minimum and material stay in registers (no LDS value slots), the primitive kind K of the
+// union's children is a template parameter (no type switch per candidate; K = FT_CARVE_MIXED keeps it), the tail's primitives have
+// wave-uniform constants (scalar loads), and the candidate lists end in a terminator record (LowerBound = +inf), so the walk carries no
+// end index.  Same operations on the same operands in the same order as ft_exec / eval_union_prims: the value is theirs bit for bit.
+//
+// Early exit ("lazy union", generalised from round 3).  With d_k <= b_k for every intersect step (b_k = the pruning bound |c_k - p| + r_k,
+// SdfForm.fs:62), `if v < b_k then v = Max(v, d_k)` equals Max(v, d_k) as a VALUE (v >= b_k >= d_k leaves v = Max(v, d_k) too), so the
+// tail maps the union's value U to max(U, m), m = the largest of the d_k / -d_k of the tail = the tail applied to -inf.  The walk's
+// running minimum only falls and ends at U <= mn; once mn <= m the scene's value is m whatever the rest of the walk finds.  The lane stops
+// there provided m > 0 and m >= the ray's epsilon (no hit at this point: the material the shortened walk reports is never read; a positive
+// value has one bit pattern), d_k <= b_k holds in this lane, and nothing is NaN (every comparison below is false for a NaN).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ft_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // IEEE minNum, -0 < +0
+__device__ __forceinline__ float ft_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// MathF.Max (ft_max: NaN propagates, -0 < +0) without branches: v_max_f32 orders the zeros and returns the other operand for a NaN
+__device__ __forceinline__ float ft_max_dev(float a, float b) {
+    const float r = ft_vmax(a, b);
+    return __builtin_isunordered(a, b) ? __builtin_nanf("") : r;
+}
+template <int K, bool FQ>
+__device__ __forceinline__ float carve_child(uint32_t typeData, cfp consts, const f3 p) {
+    cfp c = reinterpret_cast<cfp>(reinterpret_cast<const char FT_CONST*>(consts) + (size_t)(typeData >> 4));      // itemsT keeps a BYTE offset there
+    if (K == (int)FT_PR_SPHERE) return prim_sphere<FQ>(c, p);
+    if (K == (int)FT_PR_CAPSULE) return prim_capsule<FQ>(c, p);
+    if (K == (int)FT_PR_TORUS) return prim_torus<FQ>(c, p);
+    if (K == (int)FT_PR_TRIANGLE) return prim_triangle<FQ>(c, p);
+    if (K == (int)FT_PR_BOX) return prim_box(c, p);
+    return prim_eval_t<FQ>(typeData & 15u, c, p);
+}
+template <int K, bool FQ>
+__device__ __forceinline__ void carve_walk(const FtSceneDev& S, const FtCarve& CV, const f3 p, const float cap, float& outD, uint32_t& outLeaf) {
+    const FtGrid FT_CONST& g = as_const(S.grids)[0];
+    const f3 cc = (p - mk3(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2])) * mk3(g.cellSizeInv[0], g.cellSizeInv[1], g.cellSizeInv[2]);
+    const int ix = ft_clamp_i(0, g.count[0] - 1, ft_floor_i(cc.x));
+    const int iy = ft_clamp_i(0, g.count[1] - 1, ft_floor_i(cc.y));
+    const int iz = ft_clamp_i(0, g.count[2] - 1, ft_floor_i(cc.z));
+    const uint32_t cell = (uint32_t)((ix * g.count[1] + iy) * g.count[2] + iz);                  // the scene's only grid: cellBase = 0
+    cfp ctr = as_const(S.cellCenters) + 3u * cell;
+    const float distanceToCenter = ft_distance(mk3(ctr[0], ctr[1], ctr[2]), p);                   // SdfForm.fs:25
+    const char FT_CONST* items = reinterpret_cast<const char FT_CONST*>(as_const(CV.itemsT));
+    cfp consts = as_const(S.consts);
+    uint32_t off = as_const(CV.cellStartT)[cell];
+    auto rec = [&](uint32_t o) { return ld_item(reinterpret_cast<const FtItemRec FT_CONST*>(items + (size_t)o)); };
+    // Items.[0]: evaluated unconditionally (SdfForm.fs:26; SdfObject.fs:34-43 starts its pick there too)
+    float mn; uint32_t leaf;
+    {
+        const ItemRegs r0 = rec(off);
+        mn = carve_child<K, FQ>(r0.b.y, consts, p); leaf = r0.b.z;
+        off += 32u;
+    }
+    // candidate i >= 1 is evaluated iff  mn > LowerBound_i - distanceToCenter (:30)  and  mn > getMinDistance_i (:31); the list is sorted by
+    // LowerBound and mn never grows, so the first failure of :30 ends the walk (see eval_union_prims) — at the latest on the terminator
+    auto evaluate = [&](uint32_t typeData, uint32_t mat) {
+        const float d = carve_child<K, FQ>(typeData, consts, p);
+        if (d < mn) leaf = mat;                                        // SdfObject.fs:41-43
+        mn = d != d ? d : ft_vmin(mn, d);                              // SdfForm.fs:33 (mn is no NaN here: it passed :30)
+    };
+    if (!(mn <= cap)) {
+        for (;;) {
+            ItemRegs ra = rec(off), rb = rec(off + 32u);
+            asm volatile("" : "+v"(ra.a), "+v"(ra.b), "+v"(rb.a), "+v"(rb.b));      // both records requested before anything waits for either
+            const float lbA = ra.a.x - distanceToCenter, lbB = rb.a.x - distanceToCenter;
+            const float mdA = ft_dist<FQ>(mk3(ra.a.y, ra.a.z, ra.a.w), p) - __uint_as_float(ra.b.x);
+            const float mdB = ft_dist<FQ>(mk3(rb.a.y, rb.a.z, rb.a.w), p) - __uint_as_float(rb.b.x);
+            if (!(mn > lbA)) break;
+            // Both candidates of a trip are consumed: after an evaluation of A, B is judged by the new minimum with the right-hand sides computed
+            // above (they do not depend on it), so no record is requested twice.  Measured against round 3's one-evaluation-site walk (which resumes
+            // at B after evaluating A) and against a walk that requests the next trip's records one trip ahead: profiles/r04_carved_variants.txt.
+            if (mn > mdA) { evaluate(ra.b.y, ra.b.z); if (mn <= cap) break; }
+            if (!(mn > lbB)) break;
+            if (mn > mdB) { evaluate(rb.b.y, rb.b.z); if (mn <= cap) break; }
+            off += 64u;
+        }
+    }
+    outD = mn; outLeaf = leaf;
+}
+
+template <int K, bool COOP = false>
+__device__ __forceinline__ void ft_eval_carved(const FtSceneDev& S, const FtCarve& CV, const f3 p, float& outD, uint32_t& outLeaf, float epsHit) {
+    cfp consts = as_const(S.consts);
+    // the tail's primitives first: wave-uniform kinds and constants
+    float t[FT_CARVE_TAIL], b[FT_CARVE_TAIL];
+    float m = -__builtin_inff();                                       // the tail applied to -inf, as a value
+    bool lazyOk = true;
+#pragma unroll
+    for (int k = 0; k < FT_CARVE_TAIL; ++k) {
+        t[k] = 0.0f; b[k] = 0.0f;
+        if ((uint32_t)k < CV.nTail) {
+            const uint32_t op = CV.tail[k].op;
+            t[k] = prim_eval(CV.tail[k].type, consts + CV.tail[k].data, p);
+            if (op == FT_OP_ISECT_RUN) {
+                cfp bd = consts + CV.tail[k].bound;
+                b[k] = ft_distance(ld3(bd), p) + bd[3];                // SdfForm.fs:62 getMaxDistance
+                lazyOk = lazyOk && t[k] <= b[k];
+                m = ft_vmax(m, t[k]);
+            } else { lazyOk = lazyOk && t[k] == t[k]; m = ft_vmax(m, -t[k]); }
+        }
+    }
+    const float cap = (lazyOk && m >= epsHit && m > 0.0f) ? m : -__builtin_inff();      // epsHit = +inf: never
+    float v; uint32_t leaf;
+    const bool fastOk = S.fastQ != 0u && fast_point_ok(p);
+    if (COOP) {
+        // latency mode (see "Latency (tail) mode"): one query point, the same in all 64 lanes; the cell's candidates are spread over the lanes and the
+        // reference's decisions replayed in list order (eval_union_coop: the walk runs to its end, which the early exit above never changes)
+        float* none = ft_lds;                                           // no slot children in a carved scene: never dereferenced
+        if (fastOk) eval_union_coop<true, false, 0>(S, as_const(S.grids)[0], p, none, reinterpret_cast<uint32_t*>(none), none, true, false, v, leaf);
+        else eval_union_coop<false, false, 0>(S, as_const(S.grids)[0], p, none, reinterpret_cast<uint32_t*>(none), none, false, false, v, leaf);
+    }
+    else if (fastOk) carve_walk<K, true>(S, CV, p, cap, v, leaf);
+    else carve_walk<K, false>(S, CV, p, cap, v, leaf);
+#pragma unroll
+    for (int k = 0; k < FT_CARVE_TAIL; ++k) {
+        if ((uint32_t)k < CV.nTail) {
+            if (CV.tail[k].op == FT_OP_ISECT_RUN) { if (v < b[k]) v = ft_max_dev(v, t[k]); }      // SdfForm.fs:60-63
+            else v = ft_max_dev(-t[k], v);                                                        // SdfForm.fs:46-47
+        }
+    }
+    outD = v; outLeaf = leaf;
+}
+
+// ------------------------------------------------------------------------------------------------
 // render / trace kernel
 // ------------------------------------------------------------------------------------------------
 // phases >= PH_MARCH need one scene-SDF evaluation per round
@@ -1285,7 +1410,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return x;
 }
 
-template <int VARIANT, bool EXT, int MATH = 0>
+template <int VARIANT, bool EXT, int MATH = 0, int K = 0>
 __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the first wave of block 0 reports the shader clock it ran at (statistics only); its start clocks wait in LDS, not in registers
@@ -1388,7 +1513,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                     m &= m - 1ull;
                     const f3 qL = ft_readlane3(qm, L);
                     float dL; uint32_t leafL;
-                    ft_eval_coop<VARIANT == 2, MATH>(a.S, qL, sd, sl, ldsC, dL, leafL);
+                    if (VARIANT == 3) ft_eval_carved<K, true>(a.S, a.carve, qL, dL, leafL, __builtin_inff());
+                    else ft_eval_coop<VARIANT == 2, MATH>(a.S, qL, sd, sl, ldsC, dL, leafL);
                     if ((int)lane == L) { dCoop = dL; leafCoop = leafL; }
                     coopEvals += 1;
                 }
@@ -1410,6 +1536,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             else {
                 const f3 q = query_point();
                 if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf, coopRow, cullN);
+                else if (VARIANT == 3) ft_eval_carved<K>(a.S, a.carve, q, d, leaf, a.lazy == 0u ? __builtin_inff() : s.eps);
                 else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf,          // lazy unions: off (+inf) inside a glass body, whose exit is a "hit" at large values
                                                   (EXT && s.sign < 0.0f) || a.lazy == 0u ? __builtin_inff() : s.eps);
             }
@@ -1525,6 +1652,25 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_smooth_sp
 // general scenes whose unions have combinator children evaluated on demand (FT_PR_CALL, FtSceneDev.fastPath == 2)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_CALLS_OCC ft_trace_kernel_calls(const FtRenderArgs a) { ft_trace_body<2, false>(a); }
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
+// scenes that are one grid union of plain primitives of kind K with at most two intersect / subtract steps behind it (ft_device.h "Carved union":
+// the reference's own Program.fs scene is the torus one).  No exponential anywhere: no *_libm twins; EXTENSION launches take ft_trace_kernel_ext.
+// Resident waves per SIMD asked of the register allocator: 7 (72 VGPRs) where the inlined primitive fits without spills (capsules: 6, 75 registers), 5 (96) for triangles and
+// the type switch of mixed kinds (91 registers; at 6 and more they spill into the walk).  Measured: profiles/r04_carved_variants.txt.
+#define FT_CARVE_KERNEL(name, kind, waves) extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_OCC(waves) name(const FtRenderArgs a) { ft_trace_body<3, false, 0, (int)(kind)>(a); }
+FT_CARVE_KERNEL(ft_trace_kernel_carved_spheres, FT_PR_SPHERE, 7)
+FT_CARVE_KERNEL(ft_trace_kernel_carved_capsules, FT_PR_CAPSULE, 6)
+FT_CARVE_KERNEL(ft_trace_kernel_carved_tori, FT_PR_TORUS, 7)
+FT_CARVE_KERNEL(ft_trace_kernel_carved_triangles, FT_PR_TRIANGLE, 5)
+FT_CARVE_KERNEL(ft_trace_kernel_carved_mixed, FT_CARVE_MIXED, 5)
+static const void* ft_carved_kernel(unsigned kind) {
+    switch (kind) {
+        case FT_PR_SPHERE: return (const void*)ft_trace_kernel_carved_spheres;
+        case FT_PR_CAPSULE: return (const void*)ft_trace_kernel_carved_capsules;
+        case FT_PR_TORUS: return (const void*)ft_trace_kernel_carved_tori;
+        case FT_PR_TRIANGLE: return (const void*)ft_trace_kernel_carved_triangles;
+        default: return (const void*)ft_trace_kernel_carved_mixed;     // boxes (EXTENSION) and mixed kinds
+    }
+}
 // FT_OPT_MATH = glibc: the same six with MathF.Exp / Log as glibc's expf / logf (scenes that contain a unionSmooth only; every other scene
 // has no exponential and runs the kernels above whatever the option says)
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_libm(const FtRenderArgs a) { ft_trace_body<0, false, 1>(a); }
@@ -1578,6 +1724,8 @@ extern "C" __global__ void ft_math_kernel(int op, const float* __restrict__ x, c
             case 10: r = ft_glibc_powf<true>(v, y[i], ft_libm_tab_g); break;
             case 11: r = ft_glibc_powf<false>(v, y[i], ft_libm_tab_g); break;
             case 12: r = ft_pow(v, y[i]); break;
+            case 13: r = ft_max_dev(v, y[i]); break;                         // the carved kernels' MathF.Max
+            case 14: r = y[i] != y[i] ? y[i] : ft_vmin(v, y[i]); break;      // ... and their MathF.Min (first operand never NaN there)
             default: r = v / y[i]; break;
         }
         out[i] = r;
@@ -1855,7 +2003,12 @@ extern "C" hipError_t ft_launch_trace(const FtRenderArgs* a, unsigned blocks, si
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(ft_exp_fn, blocks, 1, 1, FT_BLOCK, 1, 1, (unsigned)ldsBytes, st, nullptr, extra);
     }
-#endif                                  // 0 general, 1 lean smooth-sphere, 2 general with call children
+#endif                                  // 0 general, 1 lean smooth-sphere, 2 general with call children, 3 carved union
+    if (v == 3 && !ext) {
+        FtRenderArgs args = *a;
+        void* kp[] = {&args};
+        return hipLaunchKernel(ft_carved_kernel(a->carve.kind), dim3(blocks), dim3(FT_BLOCK), kp, ldsBytes, st);
+    }
     if (v == 1 && ext) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (v == 1) hipLaunchKernelGGL(ft_trace_kernel_smooth_spheres, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
     else if (v == 2 && ext) hipLaunchKernelGGL(ft_trace_kernel_calls_ext, dim3(blocks), dim3(FT_BLOCK), ldsBytes, st, *a);
@@ -1952,7 +2105,8 @@ extern "C" hipError_t ft_debug_union_counters(unsigned long long out[12]) {
     return hipMemcpyToSymbol(HIP_SYMBOL(ft_union_dbg), zero, sizeof(zero));
 }
 #endif
-extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU) {
+extern "C" hipError_t ft_trace_occupancy(unsigned fastPath, unsigned carveKind, bool ext, bool libm, size_t ldsBytes, int* blocksPerCU) {
+    if (fastPath == 3 && !ext) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, ft_carved_kernel(carveKind), FT_BLOCK, ldsBytes);
     if (libm) {
         const void* kl = fastPath == 1 ? (ext ? (const void*)ft_trace_kernel_smooth_spheres_ext_libm : (const void*)ft_trace_kernel_smooth_spheres_libm)
                        : fastPath == 2 ? (ext ? (const void*)ft_trace_kernel_calls_ext_libm : (const void*)ft_trace_kernel_calls_libm)

@@ -695,6 +695,11 @@ struct Flattener {
 //   union      min of (a subset of) the children   ->  a sphere around the children's spheres
 //   subtract   Max(-b, a) >= a                     ->  a's sphere          (SdfForm.fs:46-47)
 //   intersect  the running Max starts at child 0   ->  child 0's sphere    (SdfForm.fs:60-63: later children may be skipped, never child 0)
+//              ... and ends >= every SPHERE child k: at step k either max < |c_k - p| + r_k and max becomes Max(max, d_k) >= d_k, or
+//              max >= |c_k - p| + r_k >= |c_k - p| - r_k = d_k (same float distance on both sides, r_k >= 0; a sphere's boundary is the
+//              sphere itself, SdfForm.fs:131-135); later steps only raise max.  So that child's own sphere serves too: the smallest wins
+//              (Program.fs:67-77: the 3.5 sphere instead of the 1000 tori's 4.7 — a quarter of the frame's evaluations belong to rays
+//              that pass the tori's sphere and miss the 3.5 one)
 //   unionSmooth  -k ln(sum exp(-d_i / k)) >= min d_i - k ln n   ->  the children's spheres grown by k ln n (needs k > 0)
 // false: no finite sphere is known (degenerate parameters, k <= 0): the scene gets none and every ray marches to its end.
 // ------------------------------------------------------------------------------------------------
@@ -719,6 +724,9 @@ static bool supportOf(const Builder& b, int h, Support& out, int depth = 0) {
     auto V = [&](size_t i) { return Support{{(double)P[i], (double)P[i + 1], (double)P[i + 2]}, 0.0}; };
     auto dist = [](const Support& a, const Support& c) { return std::sqrt((a.c[0] - c.c[0]) * (a.c[0] - c.c[0]) + (a.c[1] - c.c[1]) * (a.c[1] - c.c[1]) + (a.c[2] - c.c[2]) * (a.c[2] - c.c[2])); };
     bool ok = false;
+    // a primitive whose derived parameters are not finite (a capsule of length 0: dirInv = 0 / 0; a collinear triangle; a torus with a zero
+    // normal) evaluates to NaN everywhere; the reference's march never ends on it and both sides flag that — no shortcut for such a scene
+    if (f.isPrim()) for (float v : P) if (!std::isfinite(v)) return false;
     switch (f.kind) {
     case HostForm::SPHERE: out = V(0); out.r = std::fabs((double)P[3]); ok = true; break;                       // params: c, r
     case HostForm::CAPSULE: {                                                                                    // from, r, dir, dirInv
@@ -733,7 +741,20 @@ static bool supportOf(const Builder& b, int h, Support& out, int depth = 0) {
         out = c; ok = true; break;
     }
     case HostForm::BOX: out = V(0); out.r = std::sqrt((double)P[4] * P[4] + (double)P[5] * P[5] + (double)P[6] * P[6]); ok = true; break;   // c, -, half
-    case HostForm::SUBTRACT: case HostForm::INTERSECT: return !f.kids.empty() && supportOf(b, f.kids[0], out, depth + 1);
+    case HostForm::SUBTRACT: return !f.kids.empty() && supportOf(b, f.kids[0], out, depth + 1);
+    case HostForm::INTERSECT: {
+        if (f.kids.empty()) return false;
+        bool have = supportOf(b, f.kids[0], out, depth + 1);
+        for (size_t k = 1; k < f.kids.size(); ++k) {
+            if (!b.okForm(f.kids[k])) return false;
+            const HostForm& kf = b.forms[f.kids[k]];
+            if (kf.kind != HostForm::SPHERE) continue;
+            const std::vector<float>& Q = kf.params;
+            const bool fin = std::isfinite(Q[0]) && std::isfinite(Q[1]) && std::isfinite(Q[2]) && std::isfinite(Q[3]) && Q[3] >= 0.0f;
+            if (fin && (!have || (double)Q[3] < out.r)) { out = Support{{(double)Q[0], (double)Q[1], (double)Q[2]}, (double)Q[3]}; have = true; }
+        }
+        return have && finite3(out.c) && std::isfinite(out.r);
+    }
     case HostForm::UNION: case HostForm::SMOOTH: {
         double grow = 0.0;
         if (f.kind == HostForm::SMOOTH) {
@@ -746,6 +767,56 @@ static bool supportOf(const Builder& b, int h, Support& out, int depth = 0) {
     }
     }
     return ok && finite3(out.c) && std::isfinite(out.r);
+}
+
+// Is the program ONE grid union of plain primitives followed by at most FT_CARVE_TAIL single-primitive intersect / subtract steps
+// (ft_device.h "Carved union": the shape of Program.fs:67-77)?  Then record the tail and lay the candidate lists out with terminators.
+static bool carvedShape(FlatScene& out) {
+    if (out.nMainInstr != out.instr.size() || out.instr.empty() || out.grids.size() != 1) return false;
+    const FtInstr& u = out.instr[0];
+    if (u.op != FT_OP_UNION || u.dst != 0 || u.aux != 0) return false;
+    uint32_t kind = FT_PR_SLOT;
+    for (const FtChild& c : out.children) {
+        if (c.type > FT_PR_BOX) return false;                          // a slot or an on-demand sub-program: the general kernels
+        kind = kind == FT_PR_SLOT ? c.type : (kind == c.type ? kind : FT_CARVE_MIXED);
+    }
+    if (kind == FT_PR_SLOT) return false;
+    FtCarve cv{};
+    cv.kind = kind;
+    auto strideOf = [](uint32_t t) { return t == FT_PR_SPHERE ? FT_STRIDE_SPHERE : t == FT_PR_CAPSULE ? FT_STRIDE_CAPSULE : t == FT_PR_TORUS ? FT_STRIDE_TORUS
+                                          : t == FT_PR_TRIANGLE ? FT_STRIDE_TRIANGLE : FT_STRIDE_BOX; };
+    for (size_t k = 1; k < out.instr.size(); ++k) {
+        const FtInstr& in = out.instr[k];
+        if (in.op == FT_OP_ISECT_RUN && in.dst == 0) {
+            for (uint32_t j = 0; j < in.count; ++j) {
+                if (cv.nTail == FT_CARVE_TAIL) return false;
+                cv.tail[cv.nTail++] = FtCarveOp{FT_OP_ISECT_RUN, in.type, in.data + j * (uint32_t)strideOf(in.type), in.aux + 4u * j};
+            }
+        } else if (in.op == FT_OP_PRIM && in.dst == 1 && k + 1 < out.instr.size() && out.instr[k + 1].op == FT_OP_SUBTRACT &&
+                   out.instr[k + 1].dst == 0 && out.instr[k + 1].src == 1) {
+            if (cv.nTail == FT_CARVE_TAIL) return false;
+            cv.tail[cv.nTail++] = FtCarveOp{FT_OP_SUBTRACT, in.type, in.data, 0u};
+            ++k;
+        } else return false;
+    }
+    const size_t ncells = out.cellStart.size() - 1;
+    if ((out.items.size() + ncells + 4) * sizeof(FtItemRec) >= ((size_t)1 << 31) || out.consts.size() >= ((size_t)1 << 26)) return false;   // byte offsets stay 32-bit
+    FtItemRec stop{};
+    stop.lowerBound = INFINITY;
+    out.itemsT.clear(); out.cellStartT.clear();
+    out.itemsT.reserve(out.items.size() + ncells + 1);
+    for (size_t ci = 0; ci < ncells; ++ci) {
+        out.cellStartT.push_back((uint32_t)(out.itemsT.size() * sizeof(FtItemRec)));
+        for (uint32_t i = out.cellStart[ci]; i < out.cellStart[ci + 1]; ++i) {
+            FtItemRec r = out.items[i];
+            r.typeData = (r.typeData & 15u) | ((r.typeData >> 4) << 6);        // bits 4..: BYTE offset of the constants (the general walk keeps a float index there)
+            out.itemsT.push_back(r);
+        }
+        out.itemsT.push_back(stop);
+    }
+    for (int k = 0; k < 4; ++k) out.itemsT.push_back(stop);           // the walk requests two records at a time, and may do so one trip ahead
+    out.carve = cv;
+    return true;
 }
 
 bool flatten(const Builder& b, int object, const float bg[3], const int* lights, int nLights, FlatScene& out, std::string& err) {
@@ -772,6 +843,7 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
         else lean = false;
     }
     out.fastPath = lean ? 1u : (fl.calls.empty() ? 0u : 2u);     // kernel variant (ft_launch_trace)
+    if (out.fastPath == 0u && carvedShape(out)) out.fastPath = 3u;
     for (int i = 0; i < nLights; ++i) {
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }
         out.lights.push_back(b.lights[lights[i]].dev);

@@ -125,6 +125,10 @@ typedef enum ft_option {
     FT_OPT_LAZY_UNION = 11,       /* 1 (default): SdfForm.union as the first child of an intersect (the reference's own scene: intersect(union of tori, sphere))
                                    * stops its candidate walk at Items.[0] wherever that distance is already <= the next child's, which then decides the
                                    * intersect's value (exact; only where no hit is possible); 0: every union walk runs to its end */
+    FT_OPT_CARVED = 12,           /* 1 (default): a scene that is one SdfForm.union of primitives followed by at most two single-primitive intersect / subtract
+                                   * steps — the reference's own subtract(intersect(union tori, sphere), sphere) — is traced by a kernel specialised for that
+                                   * shape (registers instead of LDS value slots, no interpreter, the tail decides early exits of the walk; same bits);
+                                   * 0: the general interpreter kernel */
     FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's
@@ -264,7 +268,8 @@ int ft_scene_support_sphere(const ft_scene*, float centre_radius[4]);
 /* math primitives of the device path, evaluated on the GPU: op 0 exp, 1 log, 2 sqrt, 3 a/b, 4 fast sqrt, 5 fast exp
  * (y = second operand, may be NULL otherwise).  Used by tests/test_math_parity.py. */
 int ft_math_eval(ft_ctx*, int32_t op, const float* x, const float* y, int64_t n, float* out);
-/* further ops of ft_math_eval: 6 / 7 glibc expf (FMA / SSE2 build), 8 / 9 glibc logf, 10 / 11 glibc powf(x, y), 12 the fixed pow(x, y).
+/* further ops of ft_math_eval: 6 / 7 glibc expf (FMA / SSE2 build), 8 / 9 glibc logf, 10 / 11 glibc powf(x, y), 12 the fixed pow(x, y),
+ * 13 / 14 the branch-free MathF.Max(x, y) / MathF.Min(x, y) of the carved-union kernels (14: x never NaN).
  * ft_selftest_libm: checksums of the device restatement of glibc's expf (op 0), logf (1) or powf(x, y) (2) in `variant`
  * (FT_MATH_GLIBC_FMA / FT_MATH_GLIBC_SSE2) over n_chunks x 2^24 consecutive float bit patterns from lo_bits:
  * sums[c] = sum over the chunk of splitmix64((input bits << 32) | result bits) mod 2^64, every NaN result taken as 0x7fc00000.  A test forms

@@ -1305,3 +1305,91 @@ def test_render_multi_over_rccl_when_two_devices_exist(gpu):
             assert stn["rays_primary"] == st["rays_primary"] and stn["rays_shadow"] == st["rays_shadow"]
     finally:
         second.close()
+
+
+def _mathf_max(a, b):
+    """MathF.Max (IEEE 754-2019 maximum): NaN propagates, -0 < +0 (Math.fs:83; ft_math.h ft_max)"""
+    with np.errstate(all="ignore"):
+        r = np.where(a > b, a, b)
+        z = (a == b)
+        r = np.where(z & np.signbit(a), b, np.where(z, a, r))
+        return np.where(np.isnan(a) | np.isnan(b), np.float32(np.nan), r).astype(np.float32)
+
+
+def test_branch_free_min_max_of_the_carved_kernels(gpu):
+    """ft_max_dev / ft_vmin (v_max_f32 / v_min_f32 plus an unordered test) against MathF.Max / Min on every pair of a table of special values
+    and on random bit patterns: zeros of both signs, infinities, NaNs, subnormals."""
+    rng = np.random.default_rng(11)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3.4e38, -3.4e38, 0.01, -0.01], np.float32)
+    a, b = [x.ravel() for x in np.meshgrid(sp, sp)]
+    ra = rng.integers(0, 0xFFFFFFFF, 1_000_000, dtype=np.uint32).view(np.float32)
+    rb = rng.integers(0, 0xFFFFFFFF, 1_000_000, dtype=np.uint32).view(np.float32)
+    a, b = np.concatenate([a, ra, ra]), np.concatenate([b, rb, ra])
+    assert_bit_equal(gpu.math_eval(13, a, b), _mathf_max(a, b), "MathF.Max")
+    ok = ~np.isnan(a)                                                     # the walk's minimum is never NaN when it calls Min
+    want_min = -_mathf_max(-a[ok], -b[ok])
+    assert_bit_equal(gpu.math_eval(14, a[ok], b[ok]), want_min, "MathF.Min")
+
+
+def _carved_cases():
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    P = SdfForm.Primitive
+    makers = {"spheres": syn.random_sphere, "capsules": syn.random_capsule, "tori": syn.random_torus, "triangles": syn.random_triangle, "boxes": syn.random_box}
+    S1, S2, CAP = P.sphere((0.0, 0.0, 0.0), 3.2), P.sphere((-0.5, 1.0, -2.0), 2.2), P.capsule((-2.0, -1.0, -1.0), (2.0, 1.0, -1.5), 1.3)
+    BOX = P.box((0.3, -0.2, 0.0), (2.5, 2.0, 2.8))
+    tails = {"plain": lambda u: u,
+             "isect": lambda u: SdfObject.intersect(u, [S1]),
+             "sub": lambda u: SdfObject.subtract(u, S2),
+             "Program.fs": lambda u: SdfObject.subtract(SdfObject.intersect(u, [S1]), S2),
+             "sub then isect": lambda u: SdfObject.intersect(SdfObject.subtract(u, S2), [S1]),
+             "isect two": lambda u: SdfObject.intersect(u, [S1, CAP]),
+             "sub sub": lambda u: SdfObject.subtract(SdfObject.subtract(u, S2), CAP),
+             "isect box, sub capsule": lambda u: SdfObject.subtract(SdfObject.intersect(u, [BOX]), CAP)}
+    out = []
+    for ki, (kind, mk) in enumerate(makers.items()):
+        rng = syn.Rng(40 + ki)
+        objs = [mk(rng) for _ in range(120)]
+        for ti, (tn, tail) in enumerate(tails.items()):
+            if kind in ("capsules", "triangles", "boxes") and ti % 3 != ki % 3:      # every kind sees the reference's structure and a third of the rest
+                if tn != "Program.fs":
+                    continue
+            out.append((f"{kind}, {tn}", SdfScene(tail(SdfObject.union(objs)), syn.BACKGROUND, syn.program_lights())))
+    rng = syn.Rng(77)
+    mixed = [m(rng) for _ in range(30) for m in (syn.random_sphere, syn.random_torus, syn.random_capsule, syn.random_triangle)]
+    out.append(("mixed kinds, Program.fs", SdfScene(tails["Program.fs"](SdfObject.union(mixed)), syn.BACKGROUND, syn.program_lights())))
+    out.append(("mixed kinds, plain", SdfScene(SdfObject.union(mixed), syn.BACKGROUND, syn.program_lights())))
+    return out
+
+
+def test_carved_union_kernels_against_oracle(gpu, oracle):
+    """FT_OPT_CARVED (round 4): scenes that are one union of primitives plus at most two intersect / subtract steps run on kernels specialised
+    per primitive kind (kernels.hip ft_eval_carved).  Every kind x every tail: frame, counters and explicit rays (several epsilons, huge and
+    NaN origins) are the oracle's, with the kernel on and off, with and without its early exits (FT_OPT_LAZY_UNION) and the escape shortcut."""
+    cam = syn.default_camera()
+    W, H = 176, 120
+    rr = np.random.default_rng(8)
+    o = (rr.normal(size=(600, 3)) * 3.0).astype(np.float32)
+    d = rr.normal(size=(600, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    eps = rr.choice([0.01, 0.05, 0.3, 2.0, 1e-3], (600, 1)).astype(np.float32)
+    rays = np.concatenate([o, d, np.full((600, 1), 30, np.float32), eps], axis=1).astype(np.float32)
+    rays[0, 0] = np.nan; rays[1, 1] = 3e4; rays[2, 2] = -1e30; rays[3, 3:6] = 0.0; rays[4, 6] = np.inf; rays[5, 0:3] = 0.0
+    try:
+        for name, scene in _carved_cases():
+            ds, os_ = both(gpu, oracle, scene)
+            assert ds.info()["fast_path"] == 3, name
+            want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array())
+            with np.errstate(all="ignore"):
+                want_rays, want_rcnt = os_.trace_rays(rays)
+            for carved, lazy, esc in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
+                gpu.set_option("carved", carved); gpu.set_option("lazy_union", lazy); gpu.set_option("escape", esc)
+                g, gst = ds.render(EPS, LEN, ft.ImageSize(W, H), cam)
+                tag = f"{name}: carved {carved}, lazy {lazy}, escape {esc}"
+                assert_bit_equal(g, want, tag)
+                check_counts(gst, ocnt)
+                with np.errstate(all="ignore"):
+                    got_rays, rst = ds.trace_rays(rays)
+                assert_bit_equal(got_rays, want_rays, tag + " (ray buffer)")
+                assert rst["flags"] == want_rcnt["flags"], (tag, rst["flags"], want_rcnt["flags"])
+            ds.close()
+    finally:
+        gpu.set_option("carved", 1); gpu.set_option("lazy_union", 1); gpu.set_option("escape", 1)

@@ -70,13 +70,26 @@ def test_grid_matches_oracle_bitwise(host, oracle, make):
     ds.close()
 
 
+def forms_far(k):
+    return SdfForm.Primitive.sphere((10.0 + k, 0.0, 0.0), 0.5)
+
+
 def test_flattened_program_shapes(host):
     # C3: one staged fast sphere run + FIN + SETLEAF -> lean kernel variant, one value slot
     i = host.scene(syn.config3()[0]).info()
     assert (i["n_instr"], i["n_slots"], i["fast_path"], i["n_grids"]) == (3, 1, 1, 0)
-    # console scene: UNION, ISECT_RUN(sphere), PRIM(sphere), SUBTRACT -> general kernel, two slots, 1000 children
+    # console scene: UNION, ISECT_RUN(sphere), PRIM(sphere), SUBTRACT -> "carved union" kernel (3), two slots for the interpreter, 1000 children
     i = host.scene(syn.console_like(n=1000)[0]).info()
-    assert (i["n_instr"], i["n_slots"], i["fast_path"], i["n_grids"], i["n_children"], i["n_materials"]) == (4, 2, 0, 1, 1000, 1000)
+    assert (i["n_instr"], i["n_slots"], i["fast_path"], i["n_grids"], i["n_children"], i["n_materials"]) == (4, 2, 3, 1, 1000, 1000)
+    # a plain union of primitives is the same shape with an empty tail; a union with a combinator child is not
+    assert host.scene(syn.config2()[0]).info()["fast_path"] == 3
+    assert host.scene(syn.mixed_nested()[0]).info()["fast_path"] in (0, 2)
+    # three steps behind the union: more than the carved kernels' tail holds -> general kernel
+    u = SdfObject.union([syn.random_sphere(syn.Rng(1)), syn.random_sphere(syn.Rng(2))])
+    s3 = SdfObject.subtract(SdfObject.subtract(SdfObject.subtract(u, forms_far(0)), forms_far(1)), forms_far(2))
+    assert host.scene(SdfScene(s3, syn.BACKGROUND)).info()["fast_path"] == 0
+    s2 = SdfObject.subtract(SdfObject.subtract(u, forms_far(0)), forms_far(1))
+    assert host.scene(SdfScene(s2, syn.BACKGROUND)).info()["fast_path"] == 3
     # strength outside the proven range of the fast exp disables the fast path, not the scene
     forms = [SdfForm.Primitive.sphere((x, 0, 0), 0.5) for x in range(4)]
     tiny = SdfScene(SdfObject.create(SdfMaterial.createSolid((1, 1, 1)), SdfForm.unionSmooth(0.001, forms)), syn.BACKGROUND)

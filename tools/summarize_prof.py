@@ -28,11 +28,28 @@ def rows(pattern):
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f, r in rows("trace/**/*kernel_stats.csv"):
     print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+# registers per kernel from the CODE OBJECT of the library that ran (tools/kernel_resources.sh): the trace's VGPR_Count column is the
+# allocation in units of two registers (80 -> 40, 81 -> 88 allocated -> 44), which round 3's summaries printed as if it were the count
+resources = {}
+try:
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    for line in subprocess.run(["bash", os.path.join(here, "kernel_resources.sh"), _ft._lib.LIB_PATH], capture_output=True, text=True, timeout=120).stdout.splitlines():
+        w = line.split()
+        if len(w) >= 11 and w[1] == "vgpr":
+            resources[w[0]] = f"vgpr {w[2]} sgpr {w[6]} scratch {w[8]} B spilled vgprs {w[10]}"
+except Exception as e:                                             # noqa: BLE001
+    print(f"# code-object resources unavailable ({e})")
 print("== per-dispatch durations of ft_trace_kernel (ns) ==")
+seen = set()
 for f, r in rows("trace/**/*kernel_trace.csv"):
-    if "ft_trace_kernel" in r.get("Kernel_Name", ""):
-        print(r.get("Kernel_Name"), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "VGPR", r.get("VGPR_Count"), "SGPR", r.get("SGPR_Count"),
-              "LDS", r.get("LDS_Block_Size"), "grid", r.get("Grid_Size"), "wg", r.get("Workgroup_Size"))
+    name = r.get("Kernel_Name", "")
+    if "ft_trace_kernel" in name:
+        print(name, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "LDS", r.get("LDS_Block_Size"), "grid", r.get("Grid_Size_X", r.get("Grid_Size")),
+              "wg", r.get("Workgroup_Size_X", r.get("Workgroup_Size")), "scratch", r.get("Scratch_Size"))
+        seen.add(name.split("(")[0].strip())
+for name in sorted(seen):
+    print(f"code object: {name}: {resources.get(name, 'unknown')}")
 for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_ta", "pmc_tcp", "pmc_tcp2"):
     acc = defaultdict(list)
     for f, r in rows(f"{name}/**/*counter_collection.csv"):
