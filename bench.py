@@ -16,11 +16,15 @@ frame k+1 renders; all K frames are complete on rank 0 when the timed region end
 
 Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel against the f32 VALU peak
 (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s; no FMA contraction is
-allowed by the parity requirement).  `roofline.achieved / frac` price the REFERENCE's work as SURVEY.md §8d defines it — every evaluation of
-every ray marched until its Length is used up, all children in each; those counters come from one untimed launch with the escape shortcut
-off and equal the oracle's — while the timed launches run the product's defaults, which execute less, exactly (child
-culling, escape shortcut); `achieved_executed / frac_executed` price what ran, `valu_busy_pmc` is the hardware figure.  `cpu_baseline` times the CPU oracle (a C++ restatement of the
-F# CPU path — NOT the F# program) on a bounded sample of the same frame on this host's cores.
+allowed by the parity requirement).  `roofline.achieved / frac` are the HARDWARE fraction: the algorithmic lane-ops of the work the timed
+launches EXECUTED (their own exact counters: evaluations after the escape shortcut, children after the culling pass) per second over
+the peak; `valu_busy_pmc` is the counter view of the same thing.  `achieved_reference_work / frac_reference_work` price the REFERENCE's
+work as SURVEY.md §8d defines it — every evaluation of every ray marched until its Length is used up, all children in each (counters of
+one untimed launch with the escape shortcut off = the oracle's) — over the same time: an algorithmic speed-up figure, not a hardware
+fraction (rounds 1-3 printed it under `frac`).  `config.arithmetic` names the arithmetic `value` was measured in: "fixed" (the default:
+one fixed exp / log algorithm, same bits everywhere) or, with --math glibc, "glibc_fma" / "glibc_sse2" (MathF.Exp / Log as this
+host's C runtime computes them — what the reference's CPU path returns under .NET on Linux).  `cpu_baseline` times the CPU oracle (a
+C++ restatement of the F# CPU path — NOT the F# program) on a bounded sample of the same frame on this host's cores.
 """
 import argparse
 import json
@@ -91,8 +95,12 @@ def main():
     ap.add_argument("--no-reference-launch", action="store_true",
                     help="profiling passes (tools/profile.sh): skip the untimed launch that counts the reference's evaluations, so that every launch of the "
                          "trace kernel in the profile is a timed one; the roofline then prices the executed evaluation count")
+    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the side block that renders BASELINE.json config 4 (the same scene at 8192x8192, sharded the same way)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL and run the gather path in a 1-rank group")
+    ap.add_argument("--math", choices=("fixed", "glibc"), default="fixed",
+                    help="arithmetic of MathF.Exp / Log in the timed launches (FT_OPT_MATH): fixed = the library's one fixed algorithm (default), "
+                         "glibc = this host's glibc expf / logf restated on the GPU — then `value`, `roofline` and the oracle check are all in that arithmetic")
     ap.add_argument("--cpu-columns", type=int, default=0,
                     help="columns of the frame the CPU oracle is timed on (default: 32 per usable host CPU, at least 32)")
     args = ap.parse_args()
@@ -138,6 +146,9 @@ def main():
     scene, _ = syn.config3(n=args.spheres, size=W)
     cam = syn.default_camera()
     dev = ft.Device(local_rank)
+    math_variant = ft.glibc_build_of_this_host() if args.math == "glibc" else 0       # FT_MATH_GLIBC_FMA = 1, _SSE2 = 2
+    arithmetic = {0: "fixed", 1: "glibc_fma", 2: "glibc_sse2"}[math_variant]
+    dev.set_option("math", math_variant)
     stream = torch.cuda.current_stream()
     dev.set_stream(stream.cuda_stream)            # kernel, its HIP events and the collective share one stream
     ds = dev.scene(scene)
@@ -158,6 +169,7 @@ def main():
         lane_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         dev.set_stream(lane_streams[0].cuda_stream)
         dev2 = ft.Device(local_rank)
+        dev2.set_option("math", math_variant)
         dev2.set_stream(lane_streams[1].cuda_stream)
         lanes = [ds, dev2.scene(scene)]
 
@@ -243,6 +255,7 @@ def main():
         lane_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         devs2 = [ft.Device(local_rank), ft.Device(local_rank)]
         for d_, s_ in zip(devs2, lane_streams):
+            d_.set_option("math", math_variant)
             d_.set_stream(s_.cuda_stream)
         dss2 = [d_.scene(scene) for d_ in devs2]
         slabs2 = [slab, torch.empty_like(slab)]
@@ -330,7 +343,7 @@ def main():
     # the GPU, csrc/ft_libm.h) — the arithmetic the reference's CPU path would use on this very machine.  Checked further down against the
     # oracle switched to the real libm; `value` stays the default (fixed) arithmetic.
     libm = None
-    if world == 1 and pipe is None and not args.no_spp4:
+    if world == 1 and pipe is None and not args.no_spp4 and math_variant == 0:
         variant = ft.glibc_build_of_this_host()
         fixed_frame = slab.clone()
         dev.set_option("math", variant)
@@ -347,8 +360,14 @@ def main():
         same = (fixed_frame.view(torch.int32) == lib_frame.view(torch.int32)).all(dim=2)
         rays_l = (sl_["rays_primary"] + sl_["rays_shadow"]) / args.steps
         kms_l = sl_["kernel_ms"] / args.steps
-        libm = {"value": round(rays_l / kms_l / 1e3, 1), "unit": "Mrays/s", "kernel_ms": round(kms_l, 3),
+        flops_l = algorithmic_flops({"sdf_evals": sl_["sdf_evals"] // args.steps, "hits_primary": sl_["hits_primary"] // args.steps,
+                                     "rays_shadow": sl_["rays_shadow"] // args.steps}, args.spheres * (1.0 - sl_["culled_fraction"]))
+        libm = {"value": round(rays_l / kms_l / 1e3, 1), "unit": "Mrays/s", "kernel_ms": round(kms_l, 3), "arithmetic": "glibc_fma" if variant == 1 else "glibc_sse2",
                 "kernel": "ft_trace_kernel_smooth_spheres_libm", "glibc_build": "FMA" if variant == 1 else "SSE2",
+                "roofline": {"bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s", "achieved": round(flops_l / (kms_l / 1e3) / 1e12, 3),
+                             "frac": round(flops_l / (kms_l / 1e3) / 1e12 / VALU_PEAK_TLANEOPS, 4),
+                             "note": "executed work priced with the same flop counts as the headline (exp = 1 flop); this arithmetic spends ~10 double-precision "
+                                     "operations per exponential where the fixed one spends 11 single-precision ones"},
                 "fixed_vs_glibc": {"pixels_identical": round(float(same.double().mean()), 4), "pixels_over_1e-4_relative": round(float((rel > 1e-4).double().mean()), 6),
                                    "max_relative": float(rel.max())},
                 "frame": lib_frame,
@@ -357,6 +376,42 @@ def main():
                         "from it on this frame — what DESIGN.md section 2 calls the unpinnable residual"}
         slab.copy_(fixed_frame)
         del fixed_frame, a64, b64
+
+    # BASELINE.json config 4 beside the metric's config (N > 1 only): the same scene at 8192x8192 in the same interleaved column stripes, the slabs
+    # brought to rank 0 by the path's ONE gather — frame by frame, not pipelined, so that the per-rank kernel time and the gather time stand alone
+    c4 = None
+    if use_dist and not args.no_c4 and W == 4096:
+        W8 = 8192
+        size8, tiling8 = ft.ImageSize(W8, W8), ftd.tiling(W8, world, rank, STRIPE)
+        slab8 = torch.empty((W8 // world, W8, 3), dtype=torch.float32, device="cuda")
+        recv8, frame8 = ftd.gather_buffers(slab8, world, rank, args.force_dist)
+        torch.cuda.synchronize(); ds.collect_stats()
+        k8, wall8, gath8 = 2, 0.0, 0.0
+        for i in range(k8 + 1):                                       # first frame untimed
+            dist.barrier(); torch.cuda.synchronize()
+            if i == 1:
+                ds.collect_stats()
+            t8 = time.perf_counter()
+            ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size8, cam, slab8.data_ptr(), **tiling8)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            out8 = ftd.gather_frame(slab8, world, rank, STRIPE, frame=frame8, recv=recv8, force=args.force_dist)
+            torch.cuda.synchronize()
+            if i >= 1:
+                wall8 += time.perf_counter() - t8; gath8 += time.perf_counter() - tg
+        st8 = ds.collect_stats()
+        mine8 = torch.tensor([st8["kernel_ms"] / k8, gath8 / k8 * 1e3, wall8 / k8 * 1e3, float(st8["rays_primary"] + st8["rays_shadow"]) / k8],
+                             dtype=torch.float64, device="cuda")
+        all8 = [torch.empty_like(mine8) for _ in range(world)]
+        dist.all_gather(all8, mine8)
+        if rank == 0:
+            ms8 = max(float(v[2]) for v in all8)
+            c4 = {"workload": f"C4: the same scene at {W8}x{W8}, 1 spp, column stripes of {STRIPE} over {world} GPU(s) + 1 RCCL gather; frame by frame (not pipelined)",
+                  "value": round(sum(float(v[3]) for v in all8) / ms8 / 1e3, 3), "unit": "Mrays/s", "ms_per_frame": round(ms8, 3), "frames": k8,
+                  "per_rank": [{"rank": r, "kernel_ms": round(float(v[0]), 3), "gather_and_deinterleave_ms": round(float(v[1]), 3)} for r, v in enumerate(all8)],
+                  "gather_bytes_per_rank": int(slab8.numel() * 4), "frame": out8,
+                  "note": "gather time of a rank includes waiting for the slowest rank; rank 0's also the strided de-interleave copy on the device"}
+        del slab8
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = torch.tensor([st["rays_primary"], st["rays_shadow"], st["sdf_evals"], st["hits_primary"], st["flags"],
@@ -385,7 +440,8 @@ def main():
         # roofline of the dominant (only) kernel, from this rank's launches: algorithmic lane-ops per
         # launch / mean HIP-event duration of a launch
         build = ft.build_info()
-        traffic, traffic_src, valu_busy = profile_figures(build["src"], "ft_trace_kernel_smooth_spheres ") if (W == 4096 and world == 1) else (None, None, None)
+        kernel_name = "ft_trace_kernel_smooth_spheres" + ("_libm" if math_variant else "")
+        traffic, traffic_src, valu_busy = profile_figures(build["src"], "'" + kernel_name + "'") if (W == 4096 and world == 1) else (None, None, None)
         if traffic_src is None:
             traffic_src = "no profiles/*_summary.txt carries the stamp of this build (src=%s): traffic / valu_busy_pmc not quoted" % build["src"]
         # algorithmic = the reference's work: every evaluation of every ray marched to its end, every child in every evaluation (whole job; at
@@ -406,6 +462,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build": build,
             "config": {"workload": f"C3: unionSmooth(0.25) of {args.spheres} spheres, {W}x{H}, 1 spp, 1 directional light "
                                    "(shadow rays = secondary rays), eps 0.01, ray length 30",
+                       "arithmetic": arithmetic,
                        "rays_per_frame": rays // args.steps, "primary": rays_primary // args.steps,
                        "shadow": rays_shadow // args.steps, "sdf_evals_per_frame": ref_evals,
                        "sdf_evals_executed_per_frame": evals // args.steps, "children_culled_fraction": round(culled, 4),
@@ -413,21 +470,23 @@ def main():
                        "nan_or_cap_flags": flags,
                        "lane_utilisation": round(st["sdf_evals"] / (64.0 * max(1, st["wave_evals"])), 4),
                        "shader_mhz": round(st["shader_mhz"], 1)},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_reference_work": round(achieved / VALU_PEAK_TLANEOPS, 4),
+            "roofline": {"bound": "valu", "achieved": round(achieved_exec, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved_exec / VALU_PEAK_TLANEOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "achieved_executed": round(achieved_exec, 3), "frac_executed": round(achieved_exec / VALU_PEAK_TLANEOPS, 4),
+                         "achieved_reference_work": round(achieved, 3), "frac_reference_work": round(achieved / VALU_PEAK_TLANEOPS, 4),
                          "valu_busy_pmc": valu_busy,
-                         "kernel": "ft_trace_kernel_smooth_spheres",
+                         "kernel": kernel_name,
                          "kernel_ms": round(launch_s * 1e3, 3),
-                         "algorithmic_flops_per_launch": int(flops_launch),
+                         "algorithmic_flops_per_launch": int(flops_exec),
+                         "algorithmic_flops_per_launch_reference_work": int(flops_launch),
                          "shader_mhz": round(st["shader_mhz"], 1),
                          "shader_Gcycles_per_launch": round(launch_s * st["shader_mhz"] * 1e6 / 1e9, 4),
-                         "work_note": "achieved / frac (= frac_reference_work) price the REFERENCE's work (SURVEY.md section 8d: every SDF evaluation of every ray marched to its end, all "
-                                      "children in each; counters of an untimed launch with the escape shortcut off = the oracle's): an algorithmic figure.  "
-                                      "achieved_executed / frac_executed price what the kernel executes — it ends rays that can no longer reach the scene's "
-                                      "support sphere (sdf_evals_executed_per_frame) and drops, per wave and round, the children whose terms are below half "
-                                      "an ulp of the running sum (children_culled_fraction); both are exact (DESIGN.md section 4).  valu_busy_pmc is the hardware figure",
+                         "work_note": "achieved / frac (= achieved_executed / frac_executed) price what the timed launches EXECUTED — the kernel ends rays that can no "
+                                      "longer reach the scene's support sphere (sdf_evals_executed_per_frame) and drops, per wave and round, the children whose terms are "
+                                      "below half an ulp of the running sum (children_culled_fraction); both are exact (DESIGN.md section 4) — i.e. the hardware fraction, "
+                                      "next to the counter view valu_busy_pmc.  achieved_reference_work / frac_reference_work price the REFERENCE's work over the same "
+                                      "time (SURVEY.md section 8d: every SDF evaluation of every ray marched to its end, all children in each; counters of an untimed "
+                                      "launch with the escape shortcut off = the oracle's): an algorithmic speed-up figure, not a hardware fraction",
                          "note": "f32 lane-ops (FMA counted once; contraction is forbidden by parity); sqrt and exp count as 1 "
                                  "flop each although a correctly rounded sqrt / reproducible exp need 4 / 11 instructions: 26 VALU instructions "
                                  "per child against 13 algorithmic flops (the near loop's root and strength product use output modifiers inside a "
@@ -452,7 +511,7 @@ def main():
         if target is not None:
             out["config"]["north_star_target"] = target
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab if pipe is None else pipe.frame)
+            out["cpu_baseline"], check = cpu_baseline(scene, cam, W, H, args.cpu_columns, slab if pipe is None else pipe.frame, libm=math_variant != 0)
             out["config"]["max_abs_delta_vs_oracle"] = check["max_abs_delta"]      # second half of the metric: 0.0 = bit-exact
             out["config"]["pixels_compared_with_oracle"] = check["pixels"]
             if console is not None:
@@ -461,19 +520,28 @@ def main():
                 out["config"]["glibc_math_mode"] = libm_block(libm, scene, cam, W, H)
         elif world > 1:
             # N > 1: the gathered frame gets its own parity flag — a few columns against the oracle, after the timed region
-            out["config"].update(oracle_check_columns(scene, cam, W, H, pipe.frame, 16))
+            out["config"].update(oracle_check_columns(scene, cam, W, H, pipe.frame, 16, libm=math_variant != 0))
+        if c4 is not None:
+            frame8 = c4.pop("frame")
+            c4.update(oracle_check_columns(scene, cam, 8192, 8192, frame8, 8, libm=math_variant != 0))
+            out["config"]["c4_8192"] = c4
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def oracle_check_columns(scene, cam, W, H, frame, ncols):
-    """max |delta| of `ncols` evenly spaced columns of a device frame against the CPU oracle (the checker, never the thing measured)"""
+def oracle_check_columns(scene, cam, W, H, frame, ncols, libm=False):
+    """max |delta| of `ncols` evenly spaced columns of a device frame against the CPU oracle (the checker, never the thing measured);
+    libm: the oracle calls this host's real expf / logf (--math glibc)"""
     import numpy as np
     from oracle import binding as ob
     xstep = max(1, W // ncols)
-    img, _ = ob.Oracle().scene(scene).render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=host_cpu_share())
+    ob.lib.orc_set_libm(1 if libm else 0)
+    try:
+        img, _ = ob.Oracle().scene(scene).render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=host_cpu_share())
+    finally:
+        ob.lib.orc_set_libm(0)
     got = frame[::xstep].cpu().numpy()
     delta = float(np.max(np.abs(got.astype(np.float64) - img.astype(np.float64)))) if got.shape == img.shape else float("nan")
     return {"max_abs_delta_vs_oracle": delta, "pixels_compared_with_oracle": int(img.shape[0] * img.shape[1])}
@@ -481,7 +549,7 @@ def oracle_check_columns(scene, cam, W, H, frame, ncols):
 
 def program_fs_block(console, cam, steps, build_src):
     """Side block for the reference's own workload (src/FrayTracer.Console/Program.fs:14-83: System.Random(19), 1000 tori,
-    subtract(intersect(union, sphere), sphere), 2 lights) at 4000^2 on the general grid-union kernel: Mrays/s, and its own
+    subtract(intersect(union, sphere), sphere), 2 lights) at 4000^2 on the carved-union kernel of its shape (kernels.hip ft_eval_carved): Mrays/s, and its own
     roofline entry priced as SURVEY.md section 8d prescribes for unions, with the oracle's counters of a column sample of the same
     frame (the per-evaluation flop count is scaled by the kernel's exact evaluation count); the sampled columns are compared."""
     import numpy as np
@@ -505,11 +573,12 @@ def program_fs_block(console, cam, steps, build_src):
     achieved_executed = flops_per_eval_executed * evals / kernel_s / 1e12
     _, prof_src, valu_busy = profile_figures(build_src, "# case: Program.fs scene 4000^2")
     return {"workload": f"Program.fs scene, {CW}x{CW}, 1 spp, directional + point light", "value": round(rays / kernel_s / 1e6, 1), "unit": "Mrays/s",
-            "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals_ref),
+            "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel_carved_tori", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals_ref),
             "sdf_evals_executed_per_frame": int(evals), "kernel_ms_with_every_ray_marched_and_every_walk_run_to_its_end": round(console["ref_kernel_ms"], 3),
             "lane_utilisation": round(cst["sdf_evals"] / (64.0 * max(1, cst["wave_evals"])), 4), "shader_mhz": round(cst["shader_mhz"], 1),
             "max_abs_delta_vs_oracle": delta, "pixels_compared_with_oracle": int(img.shape[0] * img.shape[1]),
             "roofline": {"bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "TFLOP/s",
+                         "achieved": round(achieved_executed, 3), "frac": round(achieved_executed / VALU_PEAK_TLANEOPS, 4),
                          "achieved_reference_work": round(achieved, 3), "frac_reference_work": round(achieved / VALU_PEAK_TLANEOPS, 4),
                          "achieved_executed": round(achieved_executed, 3), "frac_executed": round(achieved_executed / VALU_PEAK_TLANEOPS, 4),
                          "valu_busy_pmc": valu_busy, "valu_busy_source": prof_src,
@@ -556,7 +625,7 @@ def host_cpu_share():
     return n
 
 
-def cpu_baseline(scene, cam, W, H, ncols, gpu_frame):
+def cpu_baseline(scene, cam, W, H, ncols, gpu_frame, libm=False):
     """Time the CPU oracle on every (W/ncols)-th column of the same frame, all host threads, and use its
     output as the checker of the GPU frame on those columns (the oracle is never the thing measured as
     `value`)."""
@@ -566,9 +635,13 @@ def cpu_baseline(scene, cam, W, H, ncols, gpu_frame):
     if ncols <= 0:
         ncols = max(32, 32 * threads)         # the oracle's work queue hands out whole columns (Array2D.fs:32)
     xstep = max(1, W // ncols)
-    t0 = time.perf_counter()
-    img, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
-    dt = time.perf_counter() - t0
+    ob.lib.orc_set_libm(1 if libm else 0)       # --math glibc: the oracle calls this host's real expf / logf, as the reference's CPU path does
+    try:
+        t0 = time.perf_counter()
+        img, cnt = osc.render(0.01, 30.0, W, H, cam.as_array(), xstep=xstep, nthreads=threads)
+        dt = time.perf_counter() - t0
+    finally:
+        ob.lib.orc_set_libm(0)
     rays = cnt["rays_primary"] + cnt["rays_shadow"]
     import numpy as np
     got = gpu_frame[::xstep].cpu().numpy()

@@ -311,17 +311,25 @@ def _vec(v):
     return _lib.Vec3(*v)
 
 
+_GLIBC_PROBES = ((0x4202422F, 0x56FC9F1C, 0x56FC9F1B), (0xC27C65D9, 0x11FA2993, 0x11FA2992))   # expf input bits, FMA build's result, SSE2 build's result
+
+
 def glibc_build_of_this_host():
-    """FT_MATH_GLIBC_FMA (1) or FT_MATH_GLIBC_SSE2 (2): which build of expf / logf / powf the C runtime of this machine resolves to —
-    glibc's x86-64 ifunc takes the FMA build iff the CPU has FMA and AVX2 (and no GLIBC_TUNABLES entry masks them).  The value to give
-    Device.set_option("math", ...) for results that equal the reference's CPU path on this host."""
-    import os
-    try:
-        flags = open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split()
-    except (OSError, IndexError):
+    """FT_MATH_GLIBC_FMA (1) or FT_MATH_GLIBC_SSE2 (2): which build of expf / logf / powf the C runtime of this machine resolves to — the
+    value to give Device.set_option("math", ...) for results that equal the reference's CPU path on this host.  Decided by asking the running
+    libm: the two builds of glibc 2.35's expf differ on exactly two of the 2^32 inputs (found by comparing the restatements of
+    csrc/ft_libm.h exhaustively; logf never differs), so expf of those two tells which one the ifunc resolver picked — whatever
+    /proc/cpuinfo, GLIBC_TUNABLES or the OS's XSAVE state made it pick.  Raises if the answers match neither build (another libm: then
+    neither glibc mode restates this host's arithmetic)."""
+    import struct
+    libm = C.CDLL("libm.so.6")
+    libm.expf.restype, libm.expf.argtypes = C.c_float, [C.c_float]
+    got = [struct.unpack("<I", struct.pack("<f", libm.expf(struct.unpack("<f", struct.pack("<I", x))[0])))[0] for x, _, _ in _GLIBC_PROBES]
+    if got == [f for _, f, _ in _GLIBC_PROBES]:
         return _lib.FT_MATH_GLIBC_FMA
-    tun = os.environ.get("GLIBC_TUNABLES", "")
-    return _lib.FT_MATH_GLIBC_FMA if ("fma" in flags and "avx2" in flags and "-FMA" not in tun and "-AVX2" not in tun) else _lib.FT_MATH_GLIBC_SSE2
+    if got == [s_ for _, _, s_ in _GLIBC_PROBES]:
+        return _lib.FT_MATH_GLIBC_SSE2
+    raise RuntimeError("this host's expf is neither build of glibc 2.35's (probe results %s): FT_OPT_MATH's glibc modes do not restate it" % [hex(g) for g in got])
 
 
 class Device:

@@ -186,7 +186,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d.nInstr = f.nMainInstr; d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
     d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ; d.nGlass = f.nGlass;
-    d.escC[0] = f.escC[0]; d.escC[1] = f.escC[1]; d.escC[2] = f.escC[2]; d.escR = f.escR;
+    d.escC[0] = f.escC[0]; d.escC[1] = f.escC[1]; d.escC[2] = f.escC[2]; d.escR = f.escR; d.escRho2 = f.escRho2;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));

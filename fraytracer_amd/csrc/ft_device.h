@@ -103,6 +103,8 @@ struct FtSceneDev {             // passed by value as kernel argument
                                 // escR < 0: none known, or FT_OPT_ESCAPE = 0
     uint32_t mathFma;           // FT_OPT_MATH (set per launch, not by the flattener): 1 = glibc's FMA build of expf / logf, 0 = its SSE2 build
                                 // (read by the *_libm kernels only)
+    float escRho2;              // the escape shortcut is taken only by rays that start within sqrt(escRho2) of escC: the bound on the float32 drift of
+                                // the marched points that escR's padding covers holds from there (scene.cpp "drift of the marched points")
 };
 
 // "Carved union" kernels (FtSceneDev.fastPath == 3; kernels.hip ft_eval_carved): the whole program is ONE grid union of plain primitives

@@ -15,7 +15,7 @@
 #else
 #define FT_LDS_DBG_ROWS 0
 #endif
-#define FT_SH_ROWS 13         // hit position, normal, accumulated light, current light's intensity (3 each), its cosine
+#define FT_SH_ROWS 9          // hit position, normal, accumulated light (3 each)
 #define FT_LDS_SH_BASE (FT_LDS_CNT_WORDS + FT_LDS_DBG_ROWS * FT_BLOCK)
 #define FT_LDS_HDR_FLOATS (FT_LDS_SH_BASE + FT_SH_ROWS * FT_BLOCK)
 // lean kernel: every wave owns a row of FT_CULL_MAX float4 records behind everything else (kernels.hip "Exact child culling").  With 256 staged

@@ -89,8 +89,11 @@ __device__ __forceinline__ void ft_flag(uint32_t bits) {              // `bits` 
 // A lane's shading state — hit position, normal (and the three probes before it), accumulated light, the current light's contribution —
 // is touched only between marches, so it lives in per-lane LDS rows (row r of thread t at FT_LDS_SH_BASE + r * FT_BLOCK + t: conflict-free),
 // not in 13 registers that would stay live across every scene evaluation: that is what lets the general kernels keep more waves resident.
-enum : uint32_t { FT_SH_HP = 0, FT_SH_NRM = 3, FT_SH_LACC = 6, FT_SH_LINT = 9, FT_SH_LCOS = 12 };
-static_assert(FT_SH_LCOS < FT_SH_ROWS, "ft_kernels.h: FT_SH_ROWS");
+// The intensity and cosine of the light a shadow ray belongs to are not kept (round 3 did: four more rows, 4 KB per workgroup — the lean kernel's fifth
+// workgroup per CU): when the ray has missed they are formed again from the light's record, the hit position and the normal, by the operations that
+// formed them when the ray was started — same operands, same roundings, same bits.
+enum : uint32_t { FT_SH_HP = 0, FT_SH_NRM = 3, FT_SH_LACC = 6 };
+static_assert(FT_SH_LACC + 3 <= FT_SH_ROWS, "ft_kernels.h: FT_SH_ROWS");
 __device__ __forceinline__ float* ft_sh(uint32_t row) { return ft_lds + FT_LDS_SH_BASE + row * FT_BLOCK + threadIdx.x; }
 __device__ __forceinline__ f3 sh_get3(uint32_t row) { const float* q = ft_sh(row); return mk3(q[0], q[FT_BLOCK], q[2 * FT_BLOCK]); }
 __device__ __forceinline__ void sh_set3(uint32_t row, f3 v) { float* q = ft_sh(row); q[0] = v.x; q[FT_BLOCK] = v.y; q[2 * FT_BLOCK] = v.z; }
@@ -1226,12 +1229,15 @@ __device__ __forceinline__ void write_ray(float* o, f3 origin, f3 dir, float len
 // |w|^2 - b^2 / |dir|^2 beyond the radius); 4e-6 |w|^2 covers the rounding of the three dot products.  Any NaN: "may still come".
 // Only for rays whose remaining march stays where float32 cannot overflow (Length < 1e9, |dir| < 1e6, distance from the sphere < 1e15): there
 // every skipped evaluation is finite, so no NaN flag (SdfForm.fs: a NaN distance never terminates; flagged by the kernel and the oracle) is lost.
+// The line is not what the reference evaluates: it accumulates the origin in float32 step by step (Ray.fs:9-13).  escR carries a padding for that
+// drift, proved sufficient (scene.cpp "drift of the marched points") for epsilon >= 0, |dir| >= 1/2 and a start within sqrt(escRho2) of the centre;
+// other rays (a point light's shadow ray has |dir| = 1 / distance, SdfLight.fs:28) simply march on and are asked again at their next step.
 __device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o, const f3 dir, float eps, float len) {
-    if (!(S.escR >= 0.0f) || !(len < 1e9f)) return false;
+    if (!(S.escR >= 0.0f) || !(len < 1e9f) || !(eps >= 0.0f)) return false;
     const f3 w = o - mk3(S.escC[0], S.escC[1], S.escC[2]);
     const float re = S.escR + eps;
     const float ww = ft_dot(w, w), cc = ww - re * re, tol = 4e-6f * ww, dd = ft_dot(dir, dir);
-    if (!(cc > tol) || !(ww < 1e30f) || !(dd < 1e12f)) return false;   // inside, too close to tell, or reaching too far for the argument above
+    if (!(cc > tol) || !(ww <= S.escRho2) || !(dd < 1e12f) || !(dd >= 0.25f)) return false;   // inside, too close to tell, or outside what the drift bound covers
     const float b = ft_dot(w, dir);
     if (b >= 0.0f) return true;
     return cc * dd - b * b > tol * dd;
@@ -1273,7 +1279,11 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
         }
         if (s.phase == PH_SHADOW) {
             if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {   // shadow ray missed (or can only miss): light arrives
-                sh_set3(FT_SH_LACC, sh_get3(FT_SH_LACC) + sh_get3(FT_SH_LINT) * *ft_sh(FT_SH_LCOS));   // SdfScene.fs:23
+                const FtLight L = ld_light(as_const(a.S.lights) + s.lidx);                 // the light this shadow ray was cast for (PH_LIGHTS below)
+                const f3 lv = mk3(L.v[0], L.v[1], L.v[2]), hp = sh_get3(FT_SH_HP);
+                f3 lint = mk3(L.color[0], L.color[1], L.color[2]), ldir = lv;             // SdfLight.fs:9, :16
+                if (L.type != FT_LIGHT_DIRECTIONAL) { ldir = ft_normalize(lv - hp); lint = lint / ft_length2(lv - hp); }      // SdfLight.fs:25, :28, :40
+                sh_set3(FT_SH_LACC, sh_get3(FT_SH_LACC) + lint * ft_dot(sh_get3(FT_SH_NRM), ldir));   // SdfScene.fs:15, :23
                 s.lidx += 1; s.phase = PH_LIGHTS;
                 continue;
             }
@@ -1289,23 +1299,21 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             }
             const FtLight L = ld_light(as_const(a.S.lights) + s.lidx);
             const f3 lv = mk3(L.v[0], L.v[1], L.v[2]);
-            const f3 lc = mk3(L.color[0], L.color[1], L.color[2]);
             f3 ldir;
             const f3 hp = sh_get3(FT_SH_HP);
             if (L.type == FT_LIGHT_DIRECTIONAL) ldir = lv;             // SdfLight.fs:9
             else ldir = ft_normalize(lv - hp);                         // SdfLight.fs:25
             const float lightCos = ft_dot(sh_get3(FT_SH_NRM), ldir);   // SdfScene.fs:15
             if (lightCos > 0.0f) {                                     // SdfScene.fs:17
-                *ft_sh(FT_SH_LCOS) = lightCos;
                 s.o = hp;
                 if (L.type == FT_LIGHT_DIRECTIONAL) {                  // SdfLight.fs:11-16
-                    s.dir = lv; s.len = 1000.0f; sh_set3(FT_SH_LINT, lc);
+                    s.dir = lv; s.len = 1000.0f;
                 } else {                                               // SdfLight.fs:27-37
                     const f3 diff = lv - hp;
                     const float distance2 = ft_length2(diff);
                     s.dir = diff / distance2;                          // not unit: reference quirk
                     s.len = sqrtf(distance2);
-                    sh_set3(FT_SH_LINT, lc / distance2);               // :40
+                                                                       // intensity lc / distance2 (:40): formed when the ray has missed (PH_SHADOW above)
                 }
                 s.steps = 0; ft_count(FT_C_SHADOW);
                 s.phase = PH_SHADOW;

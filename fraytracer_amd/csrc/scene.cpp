@@ -829,11 +829,40 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     out.nStage = fl.stageEnd <= FT_MAX_STAGE_FLOATS ? fl.stageEnd : FT_MAX_STAGE_FLOATS;
     out.nearR2 = (fl.stageEnd > 0 && fl.nearR > 0.0 && fl.nearR < 1e29) ? (float)(fl.nearR * fl.nearR * (1.0 - 1e-5)) : 0.0f;
     out.fastQ = (fl.anyUnion && fl.unionFastQ) ? 1u : 0u;
-    // the sphere no hit can lie outside of (see supportOf): grown by what float32 evaluation may differ from the exact value, 0.1 % and 0.01
+    // The sphere no hit can lie outside of (see supportOf), padded twice:
+    //   padEval  — what a float32 evaluation may differ from the exact value: 0.1 % of the radius, 0.01, and 0.1 % of the centre's coordinates;
+    //   padDrift — "drift of the marched points".  The reference moves the ray's origin step by step in float32 (Ray.fs:9-13: Origin + Direction * d), so the
+    //     points it evaluates leave the line the shortcut reasons about (kernels.hip ft_never_enters).  One step that starts or ends at most rho from the centre c
+    //     adds at most e(rho) = 3 * 2^-23 * (|c|inf + rho) to that drift (per component: the rounding of a product <= 2 rho and of a sum <= |c|inf + rho).
+    //     Let Rp = r + padEval + padDrift, a = |Direction| >= 1/2, epsilon >= 0, and suppose the drift so far is <= padDrift / 2.  Then every evaluated point
+    //     is >= r + padEval + epsilon + padDrift / 2 from c (the line stays >= escR + epsilon away), so each step is d >= g = epsilon + padDrift / 2 (support
+    //     property) and moves a d >= padDrift / 4 along the line.  Three kinds of steps:
+    //       near      (start and end within 2.5 Rp of c): the line's chord through that ball is <= 5 Rp long: at most 20 Rp / padDrift + 1 steps of error
+    //                 <= e(2.5 Rp) each.  padDrift is the root of  (20 Rp / padDrift + 1) e(2.5 Rp) = padDrift / 4.
+    //       approach  (start farther than 2.5 Rp, before the near steps): d >= rho - Rp >= rho / 2 moves >= rho / 4 along a line of which at most 2 rho are left
+    //                 to the near ball, so that length shrinks by 7/8 per step: N(rho0) = 7.5 ln(8 rho0 / padDrift) + 1 steps from a start at rho0, each
+    //                 <= e(rho0).  The kernel takes the shortcut only from starts with N(rho0) e(rho0) <= padDrift / 4 (escRho2, by bisection below).
+    //       receding  (rho >= 2.5 Rp, moving away): rho grows by >= sqrt(1 + a^2 / 4) >= 1.03 per step, so the errors form a geometric series
+    //                 < 34 * 3 * 2^-23 rho + e-terms in |c|inf that stay below rho / 100, against a margin rho - Rp - epsilon' that has grown to >= rho / 2.
+    //     Near and approach together stay <= padDrift / 2: the supposition holds step after step, every evaluated point keeps its distance, no step can be a hit.
     Support sup;
     if (supportOf(b, b.objects[object].form, sup) && sup.r < 1e15 && std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]) < 1e15) {
         out.escC[0] = (float)sup.c[0]; out.escC[1] = (float)sup.c[1]; out.escC[2] = (float)sup.c[2];
-        out.escR = (float)(sup.r * 1.001 + 0.01 + 1e-3 * (std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2])));
+        const double cInf = std::max(std::fabs(sup.c[0]), std::max(std::fabs(sup.c[1]), std::fabs(sup.c[2])));
+        const double padEval = sup.r * 0.001 + 0.01 + 1e-3 * (std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]));
+        const double u3 = 3.0 * 0x1p-23;
+        double padDrift = 0.0;
+        for (int it = 0; it < 8; ++it) {                               // padDrift^2 - k padDrift - 20 k Rp = 0 with k = 4 e(2.5 Rp), Rp depending on padDrift
+            const double Rp = sup.r + padEval + padDrift;
+            const double k = 4.0 * u3 * (cInf + 2.5 * Rp);
+            padDrift = 1.01 * (0.5 * (k + std::sqrt(k * k + 80.0 * k * Rp)));
+        }
+        out.escR = (float)((sup.r + padEval + padDrift) * (1.0 + 1e-6));
+        auto approach = [&](double rho0) { return (7.5 * std::log(8.0 * rho0 / padDrift) + 1.0) * u3 * (cInf + rho0); };
+        double lo = 0.0, hi = 1e15;                                    // largest start distance whose approach drift stays <= padDrift / 4
+        if (approach(padDrift) > 0.25 * padDrift) hi = 0.0;
+        else { lo = padDrift; for (int it = 0; it < 200; ++it) { const double mid = 0.5 * (lo + hi); (approach(mid) <= 0.25 * padDrift ? lo : hi) = mid; } }
+        out.escRho2 = (float)std::min(lo * lo * (1.0 - 1e-6), 1e30);
     }
     // kernel variant: 1 = the program is only staged fast sphere runs + SMOOTH_FIN + SETLEAF
     bool lean = !out.instr.empty() && out.nMainInstr == out.instr.size();

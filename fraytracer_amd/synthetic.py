@@ -241,8 +241,36 @@ def fuzz_scene(seed, big=False):
     solid and (EXTENSION) glass materials, 0-3 lights, a random camera and random render parameters.
     `big`: unions of 60-400 objects (large grids, the device-side grid build) and larger images.
     Returns (scene, camera, size, epsilon, extension kwargs)."""
+    scene, cam, size, eps, _, ext = _fuzz_scene(seed, big, False)
+    return scene, cam, size, eps, ext
+
+
+def fuzz_scene_edge(seed):
+    """fuzz_scene at the edge of the exact shortcuts' arguments (round 4): the whole scene (camera and lights with it) shifted by up to 7000
+    from the origin, epsilon down to 1e-5 (below the float spacing out there) and ray length up to 1000.
+    Returns (scene, camera, size, epsilon, length, extension kwargs)."""
+    return _fuzz_scene(seed, False, True)
+
+
+def _fuzz_scene(seed, big, edge):
     rng = Rng((0xB16 if big else 0xF00D) + seed)
-    P = SdfForm.Primitive
+    P0 = SdfForm.Primitive
+    off = np.zeros(3, F)
+    edge_eps, edge_len = None, RAY_LENGTH
+    if edge:
+        er = Rng(0xED6E + seed)
+        off = np.array(((0.0, 0.0, 0.0), (5000.0, -3000.0, 4000.0), (300.0, 200.0, -100.0), (-40.0, 0.0, 25.0))[int(er.range_01() * 4) % 4], F)
+        edge_eps = (1e-2, 1e-3, 1e-4, 1e-5)[int(er.range_01() * 4) % 4]
+        edge_len = (30.0, 1000.0)[int(er.range_01() * 2) % 2]
+
+    def sh(v): return np.asarray(v, F) + off                      # every position of the scene goes through the offset
+
+    class P:                                                      # the primitive constructors, shifted
+        sphere = staticmethod(lambda c, r: P0.sphere(sh(c), r))
+        capsule = staticmethod(lambda a, b, r: P0.capsule(sh(a), sh(b), r))
+        torus = staticmethod(lambda c, n, R, r: P0.torus(sh(c), n, R, r))
+        triangle = staticmethod(lambda a, b, c, r: P0.triangle(sh(a), sh(b), sh(c), r))
+        box = staticmethod(lambda c, h: P0.box(sh(c), h))
 
     def pick(n): return int(rng.range_01() * n) % n
 
@@ -290,15 +318,16 @@ def fuzz_scene(seed, big=False):
     lights = []
     for _ in range(pick(4)):
         if pick(2): lights.append(SdfLight.directional(rng.pointOnSphere(1.0), (rng.range(0.1, 1.0), rng.range(0.1, 1.0), rng.range(0.1, 1.0))))
-        else: lights.append(SdfLight.point(rng.pointOnSphere(rng.range(5.0, 9.0)), (rng.range(5, 40), rng.range(5, 40), rng.range(5, 40))))
+        else: lights.append(SdfLight.point(sh(rng.pointOnSphere(rng.range(5.0, 9.0))), (rng.range(5, 40), rng.range(5, 40), rng.range(5, 40))))
     scene = SdfScene(root, (rng.range(0.0, 0.3), rng.range(0.0, 0.3), rng.range(0.0, 0.3)), lights)
-    if pick(3) == 0: cam = default_camera()
-    else: cam = Camera.lookAt(Position=rng.pointOnSphere(rng.range(7.0, 12.0)), LookAt=rng.pointInBall(1.0), Up=(0.0, 1.0, 0.0), Lens=Lens.create(rng.range(59.0, 61.5)))
+    if pick(3) == 0: cam = default_camera() if not edge else Camera.lookAt(Position=sh((0.0, 0.0, -10.0)), LookAt=sh((0.0, 0.0, 0.0)), Up=(0.0, 1.0, 0.0), Lens=Lens.create(60.0))
+    else: cam = Camera.lookAt(Position=sh(rng.pointOnSphere(rng.range(7.0, 12.0))), LookAt=sh(rng.pointInBall(1.0)), Up=(0.0, 1.0, 0.0), Lens=Lens.create(rng.range(59.0, 61.5)))
     size = ImageSize(24 + 8 * pick(5), 24 + 8 * pick(5)) if not big else ImageSize(64 + 16 * pick(5), 64 + 16 * pick(5))
     eps = (0.01, 0.003, 0.03)[pick(3)]
+    if edge_eps is not None: eps = edge_eps
     ext = {}
     if pick(2):
         spp = (1, 4)[pick(2)]
         ext = dict(spp=spp, ao_samples=(0, 0, 3, 7)[pick(4)], ao_radius=float(rng.range(0.3, 1.5)), max_bounces=(0, 2, 4, 7)[pick(4)],
                    spectral=(0, 1, 2, 4)[pick(4)] if spp == 4 else (0, 1)[pick(2)])
-    return scene, cam, size, eps, ext
+    return scene, cam, size, eps, edge_len, ext

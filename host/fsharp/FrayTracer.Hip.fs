@@ -121,9 +121,17 @@ module Native =
     let check (h : int) =
         if h < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ())) else h
 
-type GpuForm = { Form : FrayTracer.SdfForm; Node : int }
+// The reference's closures are built LAZILY (round 4): FrayTracer.SdfForm.union / SdfObject.union run the O(cells x items) buildSpatialLookup on the
+// CPU (SdfBoundary.fs:225-274, called at SdfForm.fs:19 and again at SdfObject.fs:26) — seconds for the 1000 tori of Program.fs, before a GPU frame of
+// 1.3 ms.  `.Form` / `.Object` force them on first use (renderSceneCpu, or a caller mixing both paths); a scene that is only rendered on
+// the GPU never builds them.  The native handle is made eagerly: it is what Image.renderScene needs.
+type GpuForm =
+    { FormCpu : Lazy<FrayTracer.SdfForm>; Node : int }
+    member this.Form = this.FormCpu.Value
 type GpuMaterial = { Material : FrayTracer.SdfMaterial; Node : int }
-type GpuObject = { Object : FrayTracer.SdfObject; Node : int }
+type GpuObject =
+    { ObjectCpu : Lazy<FrayTracer.SdfObject>; Node : int }
+    member this.Object = this.ObjectCpu.Value
 type GpuLight = { Light : FrayTracer.SdfLight; Node : int }
 type GpuScene = { Object : GpuObject; BackgroundColor : FColor; Lights : GpuLight list }        // Types.fs:74-79
 
@@ -135,34 +143,34 @@ module SdfForm =
     module Primitive =
         let sphere (data : FrayTracer.SdfForm.Primitive.Sphere) =                                           // SdfForm.fs:125-135
             let mutable d = data
-            { Form = FrayTracer.SdfForm.Primitive.sphere data; Node = Native.check (Native.ft_form_sphere (Native.ctx.Value, &d)) }
+            { FormCpu = lazy (FrayTracer.SdfForm.Primitive.sphere data); Node = Native.check (Native.ft_form_sphere (Native.ctx.Value, &d)) }
         let capsule (data : FrayTracer.SdfForm.Primitive.Capsule) =                                         // SdfForm.fs:145-170
             let mutable d = data
-            { Form = FrayTracer.SdfForm.Primitive.capsule data; Node = Native.check (Native.ft_form_capsule (Native.ctx.Value, &d)) }
+            { FormCpu = lazy (FrayTracer.SdfForm.Primitive.capsule data); Node = Native.check (Native.ft_form_capsule (Native.ctx.Value, &d)) }
         let torus (data : FrayTracer.SdfForm.Primitive.Torus) =                                             // SdfForm.fs:181-203
             let mutable d = data
-            { Form = FrayTracer.SdfForm.Primitive.torus data; Node = Native.check (Native.ft_form_torus (Native.ctx.Value, &d)) }
+            { FormCpu = lazy (FrayTracer.SdfForm.Primitive.torus data); Node = Native.check (Native.ft_form_torus (Native.ctx.Value, &d)) }
         let triangle (data : FrayTracer.SdfForm.Primitive.Triangle) =                                       // SdfForm.fs:214-268
             let mutable d = data
-            { Form = FrayTracer.SdfForm.Primitive.triangle data; Node = Native.check (Native.ft_form_triangle (Native.ctx.Value, &d)) }
+            { FormCpu = lazy (FrayTracer.SdfForm.Primitive.triangle data); Node = Native.check (Native.ft_form_triangle (Native.ctx.Value, &d)) }
 
     let union (forms : seq<GpuForm>) =                                                           // SdfForm.fs:14-40
         match forms |> Seq.toArray with
         | [||] -> failwith "No SdfObjects given."
         | [| form |] -> form
         | forms ->
-            { Form = forms |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.union
+            { FormCpu = lazy (forms |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.union)
               Node = Native.check (Native.ft_form_union (c (), nodes forms, forms.Length)) }
 
     let subtract (a : GpuForm) (b : GpuForm) =                                                   // SdfForm.fs:42-49
-        { Form = FrayTracer.SdfForm.subtract a.Form b.Form; Node = Native.check (Native.ft_form_subtract (c (), a.Node, b.Node)) }
+        { FormCpu = lazy (FrayTracer.SdfForm.subtract a.Form b.Form); Node = Native.check (Native.ft_form_subtract (c (), a.Node, b.Node)) }
 
     let intersect (forms : seq<GpuForm>) =                                                       // SdfForm.fs:51-67
         match forms |> Seq.toArray with
         | [||] -> failwith "No SdfObjects given."
         | [| form |] -> form
         | forms ->
-            { Form = forms |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.intersect
+            { FormCpu = lazy (forms |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.intersect)
               Node = Native.check (Native.ft_form_intersect (c (), nodes forms, forms.Length)) }
 
     let unionSmooth (strength : float32) (forms : seq<GpuForm>) =                                // SdfForm.fs:69-91
@@ -170,7 +178,7 @@ module SdfForm =
         | [||] -> failwithf "blub"
         | [| sdf |] -> sdf
         | sdfs ->
-            { Form = sdfs |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.unionSmooth strength
+            { FormCpu = lazy (sdfs |> Seq.map (fun f -> f.Form) |> FrayTracer.SdfForm.unionSmooth strength)
               Node = Native.check (Native.ft_form_union_smooth (c (), strength, nodes sdfs, sdfs.Length)) }
 
 [<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]
@@ -190,7 +198,7 @@ module SdfObject =
     let private c () = Native.ctx.Value
 
     let create (material : GpuMaterial) (form : GpuForm) : GpuObject =                           // SdfObject.fs:6-10
-        { Object = FrayTracer.SdfObject.create material.Material form.Form
+        { ObjectCpu = lazy (FrayTracer.SdfObject.create material.Material form.Form)
           Node = Native.check (Native.ft_object_create (c (), material.Node, form.Node)) }
 
     let union (objects : seq<GpuObject>) : GpuObject =                                           // SdfObject.fs:12-48
@@ -199,17 +207,17 @@ module SdfObject =
         | [| o |] -> o
         | objects ->
             let nodes = objects |> Array.map (fun o -> o.Node)
-            { Object = objects |> Seq.map (fun o -> o.Object) |> FrayTracer.SdfObject.union
+            { ObjectCpu = lazy (objects |> Seq.map (fun o -> o.Object) |> FrayTracer.SdfObject.union)
               Node = Native.check (Native.ft_object_union (c (), nodes, nodes.Length)) }
 
     let subtract (object : GpuObject) (form : GpuForm) : GpuObject =                             // SdfObject.fs:50-54
-        { Object = FrayTracer.SdfObject.subtract object.Object form.Form
+        { ObjectCpu = lazy (FrayTracer.SdfObject.subtract object.Object form.Form)
           Node = Native.check (Native.ft_object_subtract (c (), object.Node, form.Node)) }
 
     let intersect (object : GpuObject) (forms : seq<GpuForm>) : GpuObject =                      // SdfObject.fs:56-64
         let forms = forms |> Seq.toArray
         let nodes = forms |> Array.map (fun f -> f.Node)
-        { Object = FrayTracer.SdfObject.intersect object.Object (forms |> Seq.map (fun f -> f.Form))
+        { ObjectCpu = lazy (FrayTracer.SdfObject.intersect object.Object (forms |> Seq.map (fun f -> f.Form)))
           Node = Native.check (Native.ft_object_intersect (c (), object.Node, nodes, nodes.Length)) }
 
 [<CompilationRepresentation(CompilationRepresentationFlags.ModuleSuffix)>]

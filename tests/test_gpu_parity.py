@@ -1393,3 +1393,105 @@ def test_carved_union_kernels_against_oracle(gpu, oracle):
             ds.close()
     finally:
         gpu.set_option("carved", 1); gpu.set_option("lazy_union", 1); gpu.set_option("escape", 1)
+
+
+def _offset_scenes(off):
+    """three small scenes of different kernel families around the point `off`: the reference's structure (carved union), a smooth union of
+    spheres (lean kernel) and a union with a combinator child (general kernel)"""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    P = SdfForm.Primitive
+    off = np.asarray(off, np.float32)
+    rng = syn.Rng(91)
+    mat = [SdfMaterial.createSolid((0.3 + 0.1 * i, 0.8 - 0.1 * i, 0.4)) for i in range(4)]
+    at = lambda v: tuple((np.asarray(v, np.float32) + off).tolist())
+    tori = [SdfObject.create(mat[i % 4], P.torus(at(rng.pointInBall(2.0)), rng.pointOnSphere(1.0), rng.range(0.2, 0.5), rng.range(0.1, 0.2))) for i in range(40)]
+    carved = SdfObject.subtract(SdfObject.intersect(SdfObject.union(tori), [P.sphere(at((0, 0, 0)), 1.8)]), P.sphere(at((-0.3, 0.6, -1.2)), 1.2))
+    blob = SdfObject.create(mat[0], SdfForm.unionSmooth(0.25, [P.sphere(at(rng.pointInBall(1.5)), rng.range(0.2, 0.5)) for _ in range(24)]))
+    nested = SdfObject.union([SdfObject.create(mat[1], SdfForm.subtract(P.sphere(at((0.5, 0, 0)), 1.0), P.sphere(at((0.9, 0.2, -0.4)), 0.6))),
+                              SdfObject.create(mat[2], P.capsule(at((-1.5, -0.5, 0)), at((-0.5, 0.8, 0.3)), 0.3)), SdfObject.create(mat[3], P.sphere(at((0, -1.2, 0.4)), 0.5))])
+    lights = [SdfLight_dir(), SdfLight_point(at((-0.5, 0.0, -2.0)))]
+    return [("carved", SdfScene(carved, syn.BACKGROUND, lights)), ("smooth", SdfScene(blob, syn.BACKGROUND, lights)), ("nested", SdfScene(nested, syn.BACKGROUND, lights))]
+
+
+def SdfLight_dir():
+    from fraytracer_amd import SdfLight
+    return SdfLight.directional((-0.5, -1.0, 1.0), (0.5, 0.5, 0.5))
+
+
+def SdfLight_point(pos):
+    from fraytracer_amd import SdfLight
+    return SdfLight.point(pos, (10.0, 0.0, 0.0))
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (5000.0, -3000.0, 4000.0)])
+def test_escape_shortcut_at_its_edge(gpu, oracle, offset):
+    """The escape shortcut reasons about the ideal line while the reference accumulates the origin in float32 (Ray.fs:9-13); its padding is
+    proved to cover that drift (scene.cpp "drift of the marched points").  Probe where the proof is thinnest: rays tangent to the support sphere
+    within +-2 paddings, tiny epsilons (1e-4, 1e-5: below the float spacing at |c| = 7000), Length 1000, starts from just outside to 50 radii away,
+    unit and non-unit directions (a point light's shadow direction is diff / |diff|^2), scenes 7000 away from the origin.  Colours, ray / hit
+    counters and flags must be the oracle's with the shortcut on and off — the oracle has no shortcut at all."""
+    rng = np.random.default_rng(5)
+    try:
+        for name, scene in _offset_scenes(offset):
+            ds, os_ = both(gpu, oracle, scene)
+            cx, cy, cz, R = ds.support_sphere()
+            assert R > 0, name
+            c = np.array([cx, cy, cz], np.float64)
+            n = 360
+            u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+            start = c + u * R * rng.choice([1.02, 1.5, 3.0, 10.0, 50.0], (n, 1))
+            # aim at a point whose distance from the centre is R + epsilon + k paddings, in a random direction perpendicular to the start direction
+            v = np.cross(u, rng.normal(size=(n, 3))); v /= np.linalg.norm(v, axis=1, keepdims=True)
+            eps = rng.choice([1e-2, 1e-4, 1e-5], (n, 1))
+            pad = max(0.02, 0.01 * R)
+            miss = R + eps + rng.uniform(-2.0, 2.0, (n, 1)) * pad
+            miss[180:240] = rng.uniform(0.0, 1.0, (60, 1)) * min(R, 2.5)           # ... and a family through the scene itself (hits, shadow rays of both lights)
+            target = c + v * miss
+            d = target - start; d /= np.linalg.norm(d, axis=1, keepdims=True)
+            d[240:300] *= rng.choice([0.2, 0.5, 3.0, 17.0], (60, 1))              # non-unit directions, as SdfLight.point casts them
+            d[300:330] *= -1.0                                                     # pointing away
+            length = rng.choice([30.0, 1000.0], (n, 1))
+            rays = np.concatenate([start, d, length, eps], axis=1).astype(np.float32)
+            with np.errstate(all="ignore"):
+                want, ocnt = os_.trace_rays(rays)
+            evals = {}
+            for esc in (1, 0):
+                gpu.set_option("escape", esc)
+                with np.errstate(all="ignore"):
+                    got, gst = ds.trace_rays(rays)
+                assert_bit_equal(got, want, f"{name} at {offset}, escape {esc}")
+                for k in ("rays_shadow", "hits_primary", "hits_shadow", "flags"):
+                    assert gst[k] == ocnt[k], (name, offset, esc, k, gst[k], ocnt[k])
+                evals[esc] = gst["sdf_evals"]
+            assert evals[1] <= evals[0], (name, evals)
+            if name == "carved" and offset == (0.0, 0.0, 0.0):
+                assert evals[1] < evals[0], evals                                  # the shortcut is alive (not gated away) where it matters
+            ds.close()
+    finally:
+        gpu.set_option("escape", 1)
+
+
+def test_a_scene_of_nan_constants_takes_no_escape_shortcut(gpu, oracle):
+    """A capsule of length 0 (dirInv = 0 / 0) or a collinear triangle evaluates to NaN everywhere; the reference's march never ends on such a
+    value and both sides raise the NaN flag.  Such a scene gets no support sphere (scene.cpp supportOf), so a ray that would have been ended
+    early still meets the NaN and reports it: flags are the oracle's with the shortcut on and off."""
+    from fraytracer_amd import SdfForm, SdfObject, SdfMaterial, SdfScene
+    P = SdfForm.Primitive
+    m = SdfMaterial.createSolid((0.5, 0.5, 0.5))
+    for bad in (P.capsule((1.0, 0.0, 0.0), (1.0, 0.0, 0.0), 0.2), P.triangle((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (2.0, 2.0, 2.0), 0.1)):
+        scene = SdfScene(SdfObject.union([SdfObject.create(m, bad), SdfObject.create(m, P.sphere((0.0, 0.0, 0.0), 0.5))]), syn.BACKGROUND, syn.program_lights())
+        ds, os_ = both(gpu, oracle, scene)
+        assert ds.support_sphere()[3] < 0
+        rays = np.array([[0, 0, -5, 0, 0, 1, 30, 0.01], [0, 3, -5, 0, 0, 1, 30, 0.01], [4, 0, 0, 1, 0, 0, 30, 0.01], [0, 0, -5, 0, 0, -1, 30, 0.01]], np.float32)
+        with np.errstate(all="ignore"):
+            want, ocnt = os_.trace_rays(rays)
+        try:
+            for esc in (1, 0):
+                gpu.set_option("escape", esc)
+                with np.errstate(all="ignore"):
+                    got, gst = ds.trace_rays(rays)
+                assert_bit_equal(got, want, f"NaN constants, escape {esc}")
+                assert gst["flags"] == ocnt["flags"] and (ocnt["flags"] & 1), (esc, gst["flags"], ocnt["flags"])
+        finally:
+            gpu.set_option("escape", 1)
+        ds.close()
