@@ -82,7 +82,7 @@ class TonemapParams(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n_instr", "n_slots", "n_consts", "n_grids", "n_children", "n_cells",
-                                          "n_items", "n_lights", "n_materials", "fast_path")]
+                                          "n_items", "n_lights", "n_materials", "fast_path", "cull_pc")]
 
 
 # every symbol include/fraytracer_hip.h declares: name -> (restype, argtypes)

@@ -186,7 +186,7 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
     d.nInstr = f.nMainInstr; d.nSlots = f.nSlots; d.nLights = (uint32_t)f.lights.size(); d.fastPath = f.fastPath;
     d.bg[0] = f.bg[0]; d.bg[1] = f.bg[1]; d.bg[2] = f.bg[2];
     d.nStage = f.nStage; d.nearR2 = f.nearR2; d.fastQ = f.fastQ; d.nGlass = f.nGlass;
-    d.escC[0] = f.escC[0]; d.escC[1] = f.escC[1]; d.escC[2] = f.escC[2]; d.escR = f.escR; d.escRho2 = f.escRho2;
+    d.escC[0] = f.escC[0]; d.escC[1] = f.escC[1]; d.escC[2] = f.escC[2]; d.escR = f.escR; d.escRho2 = f.escRho2; d.cullPc = f.cullPc;
     if (!c->hasDevice) return FT_OK;                       // host-only context: introspection only
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&s->dBlob, cur));
@@ -220,7 +220,8 @@ size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false, 
     const size_t nSlots = (traceLaunch && (variant == 1u || variant == 3u)) ? 0 : s->dev.nSlots;       // the lean and the carved kernels keep their values in registers
     size_t floats = (size_t)FT_LDS_HDR_FLOATS + nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
     if (libm) floats = ((floats + 1) & ~(size_t)1) + (size_t)FT_LIBM_TAB_DOUBLES * 2;
-    if (s->dev.fastPath == 1u) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
+    // one row per wave behind everything: the lean kernel's latency mode and culled children; any other trace kernel's culled children where the scene has a cull site
+    if (s->dev.fastPath == 1u || (traceLaunch && variant != 3u && s->dev.cullPc != 0xffffffffu)) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
     return floats * 4;
 }
 // Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
@@ -310,7 +311,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.carve = s->carve;
     if (variant == 1u || variant == 3u) a.S.nSlots = 0;    // the lean and carved kernels use no value slots: their LDS layout has none (ldsBytes)
     a.math = libm ? 1u : 0u;
-    a.cull = (s->dev.fastPath == 1u && c->optCull) ? 1u : 0u;
+    a.cull = (s->dev.cullPc != 0xffffffffu && variant != 3u && c->optCull) ? 1u : 0u;
     if (!c->optEscape) a.S.escR = -1.0f;
     a.lazy = c->optLazyUnion ? 1u : 0u;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
@@ -956,6 +957,7 @@ int ft_scene_info_get(const ft_scene* s, ft_scene_info* o) {
     o->n_grids = (int32_t)f.grids.size(); o->n_children = (int32_t)f.children.size(); o->n_cells = (int32_t)(f.cellCenters.size() / 3);
     o->n_items = (int32_t)f.items.size(); o->n_lights = (int32_t)f.lights.size(); o->n_materials = (int32_t)(f.materials.size() / 3);
     o->fast_path = (int32_t)f.fastPath;
+    o->cull_pc = (int32_t)f.cullPc;
     return FT_OK;
 }
 

@@ -103,6 +103,8 @@ struct FtSceneDev {             // passed by value as kernel argument
                                 // escR < 0: none known, or FT_OPT_ESCAPE = 0
     uint32_t mathFma;           // FT_OPT_MATH (set per launch, not by the flattener): 1 = glibc's FMA build of expf / logf, 0 = its SSE2 build
                                 // (read by the *_libm kernels only)
+    uint32_t cullPc;            // instruction of the main program whose sphere run the child-culling pass serves (kernels.hip "Exact child culling"): a staged fast
+                                // SMOOTH_RUN of >= 32 children, the longest one; 0xffffffff: none
     float escRho2;              // the escape shortcut is taken only by rays that start within sqrt(escRho2) of escC: the bound on the float32 drift of
                                 // the marched points that escR's padding covers holds from there (scene.cpp "drift of the marched points")
 };

@@ -513,11 +513,13 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
     outD = mn; outLeaf = leaf;
 }
 
+#define FT_CULL_NONE 0xffffffffu
 // the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
 template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
-                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, float epsHit = __builtin_inff());
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, float epsHit = __builtin_inff(),
+                                        const float* __restrict__ cullRow = nullptr, uint32_t cullN = FT_CULL_NONE);
 
 template <bool FQ, int MATH>
 __device__ __forceinline__ void eval_union(const FtSceneDev& S, const FtGrid FT_CONST& g, const f3 p,
@@ -659,7 +661,8 @@ __device__ __forceinline__ void eval_union_coop(const FtSceneDev& S, const FtGri
 
 template <bool WITH_UNION, bool CALLS, int MATH, bool COOP>
 __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32_t pcEnd, const f3 p, float* __restrict__ sd,
-                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, float epsHit) {
+                                        uint32_t* __restrict__ sl, const float* __restrict__ ldsC, bool fastOk, bool nearOk, float epsHit,
+                                        const float* __restrict__ cullRow, uint32_t cullN) {
     cfp consts = as_const(S.consts);
     for (; pc < pcEnd; ++pc) {
         const FtInstr in = ld_instr(as_const(S.instr) + pc);
@@ -674,10 +677,21 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
         case FT_OP_SMOOTH_RUN: {                                       // SdfForm.fs:77-80
             float sum = (in.flags & 1u) ? 0.0f : *dst;
             if (fastOk && S.nStage != 0 && (in.flags & FT_FLAG_FAST) && in.data + 4u * in.count <= S.nStage) {
-                if (MATH != 0) sum = S.mathFma ? smooth_run_spheres_libm<true, true>(ldsC + in.data, in.count, in.f0, p, sum, ft_libm_tab(S))
-                                               : smooth_run_spheres_libm<false, true>(ldsC + in.data, in.count, in.f0, p, sum, ft_libm_tab(S));
-                else sum = nearOk ? smooth_run_spheres_fast<true>(ldsC + in.data, in.count, in.f0, p, sum)
-                                  : smooth_run_spheres_fast<false>(ldsC + in.data, in.count, in.f0, p, sum);
+                // the run — or, where the culling pass ran for this wave and round (pc = FtSceneDev.cullPc), the survivors of its first FT_CULL_MAX children
+                // from the wave's LDS row and then the rest of the run in full ("Exact child culling" below; the lean kernel does the same)
+                const bool culled = pc == S.cullPc && cullN != FT_CULL_NONE;
+                const float* c = culled ? cullRow : ldsC + in.data;
+                uint32_t n = culled ? cullN : in.count;
+                uint32_t rest = culled && in.count > FT_CULL_MAX ? in.count - FT_CULL_MAX : 0u;
+#pragma nounroll
+                for (;;) {
+                    if (MATH != 0) sum = S.mathFma ? smooth_run_spheres_libm<true, true>(c, n, in.f0, p, sum, ft_libm_tab(S))
+                                                   : smooth_run_spheres_libm<false, true>(c, n, in.f0, p, sum, ft_libm_tab(S));
+                    else sum = nearOk ? smooth_run_spheres_fast<true>(c, n, in.f0, p, sum)
+                                      : smooth_run_spheres_fast<false>(c, n, in.f0, p, sum);
+                    if (rest == 0u) break;
+                    c = ldsC + in.data + 4u * FT_CULL_MAX; n = rest; rest = 0u;
+                }
             } else {
                 cfp c = consts + in.data;
                 const uint32_t stride = prim_stride(in.type);
@@ -751,10 +765,11 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
 
 template <bool CALLS, int MATH>
 __device__ __forceinline__ void ft_eval(const FtSceneDev& S, const f3 p, float* __restrict__ sd, uint32_t* __restrict__ sl,
-                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf, float epsHit = __builtin_inff()) {
+                                        const float* __restrict__ ldsC, float& outD, uint32_t& outLeaf, float epsHit = __builtin_inff(),
+                                        const float* __restrict__ cullRow = nullptr, uint32_t cullN = FT_CULL_NONE) {
     const bool fastOk = (S.nStage != 0 || S.fastQ != 0) && fast_point_ok(p);
     const bool nearOk = MATH == 0 && fastOk && S.nStage != 0 && near_point_ok(p, S.nearR2);
-    ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk, epsHit);
+    ft_exec<true, CALLS, MATH>(S, 0u, S.nInstr, p, sd, sl, ldsC, fastOk, nearOk, epsHit, cullRow, cullN);
     outD = sd[0];
     outLeaf = sl[0];
 }
@@ -796,8 +811,7 @@ __device__ __forceinline__ void ft_eval_coop(const FtSceneDev& S, const f3 p, fl
 // ------------------------------------------------------------------------------------------------
 // FT_CULL_MAX (ft_kernels.h): children per culling pass = float4 records of the wave's LDS row; a longer run's tail is evaluated in full.
 // FT_CULL_ROW: floats of that row; its first FT_COOP_SEG floats double as the latency mode's row (never used in the same round).
-#define FT_CULL_MIN 32u                        // runs shorter than this are not worth the pass
-#define FT_CULL_NONE 0xffffffffu
+#define FT_CULL_MIN 32u                        // runs shorter than this are not worth the pass (scene.cpp picks FtSceneDev.cullPc accordingly)
 __device__ __forceinline__ f3 ft_readlane3(f3 v, int l) {
     return mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), l)),
                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), l)));
@@ -824,14 +838,17 @@ __device__ __forceinline__ float ft_wave_scan_incl(float v, float& total) {     
     return v;
 }
 __device__ __forceinline__ float ft_wave_shift_right1(float v) { return ft_dpp<0x138>(0.0f, v); }   // wave_shr:1; lane 0 gets 0
-// -> survivors among the first min(count, FT_CULL_MAX) children of instruction 0, their records in row[0 ..), or FT_CULL_NONE (row untouched).
+// -> survivors among the first min(count, FT_CULL_MAX) children of instruction FtSceneDev.cullPc, their records in row[0 ..), or FT_CULL_NONE (row untouched).
+// A run that continues an accumulator (no FT_FLAG_INIT: children of other kinds came first) starts from a sum >= 0, so the prefix sums of the run's own lower
+// bounds are still lower bounds of the running sum in front of each of its children.
 // active / am: lanes that evaluate p this round (am = __ballot(active) != 0).  Wave-uniform result; executed by all 64 lanes.
 __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const f3 p, bool active, unsigned long long am,
                                                      const float* __restrict__ ldsC, float* __restrict__ row) {
-    const FtInstr FT_CONST* in = as_const(S.instr);
+    if (S.cullPc == FT_CULL_NONE) return FT_CULL_NONE;
+    const FtInstr FT_CONST* in = as_const(S.instr) + S.cullPc;
     const uint32_t flags = in->flags, count = in->count;
     const float si = in->f0;
-    if (in->op != FT_OP_SMOOTH_RUN || (flags & (FT_FLAG_INIT | FT_FLAG_FAST)) != (FT_FLAG_INIT | FT_FLAG_FAST) || count < FT_CULL_MIN || !(si < 0.0f)) return FT_CULL_NONE;
+    if (in->op != FT_OP_SMOOTH_RUN || !(flags & FT_FLAG_FAST) || count < FT_CULL_MIN || !(si < 0.0f)) return FT_CULL_NONE;
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p.x), __builtin_fabsf(p.y)), __builtin_fabsf(p.z));
     const bool bad = !(m < FT_FAST_P_MAX) || p.x != p.x || p.y != p.y || p.z != p.z;
     if (__ballot(active && bad) != 0ull) return FT_CULL_NONE;         // such evaluations take the exact loop anyway
@@ -924,7 +941,7 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
             acc = (in->flags & FT_FLAG_INIT) ? 0.0f : acc;
             // the run, or — where ft_cull_children ran for this wave and round — the survivors of its first FT_CULL_MAX children (in the wave's
             // LDS row) and then the rest of the run in full; one inlined copy of the loops serves both pieces
-            const bool culled = pc == 0u && cullN != FT_CULL_NONE && fastOk;
+            const bool culled = pc == S.cullPc && cullN != FT_CULL_NONE && fastOk;
             const float* c = culled ? cullRow : ldsC + in->data;
             uint32_t n = culled ? cullN : in->count;
             uint32_t rest = culled && in->count > FT_CULL_MAX ? in->count - FT_CULL_MAX : 0u;
@@ -1188,10 +1205,15 @@ struct LaneState {
     float len, eps;
     // in LDS (ft_sh rows), not here: hp = result.Ray.Origin after Ray.move -eps (SdfObject.fs:73) = result.Position; nrm = the three probes
     // NX..NZ, afterwards the normal; lacc = lightColor (SdfScene.fs:12); lint = intensity the current light adds when unshadowed; lcos
-    uint32_t aoIdx, aoOpen;   // EXTENSION: ambient-occlusion ray counter / unoccluded count
-    float sign;               // EXTENSION glass: +1 outside, -1 inside (the march runs on sign * Distance)
+    // EXTENSION state, one register (round 3 kept four: the EXTENSION build of the general kernel spilled three at its 96): bits 0-7 the ambient-occlusion
+    // ray counter (<= 16), 8-15 the unoccluded count, 16-23 glass interactions so far (<= 64), 31 set = inside a glass body (the march runs on -Distance)
+    uint32_t xs;
     f3 thr;                   // EXTENSION: path throughput (wavelength weight x tints)
-    uint32_t bounce, seed;    // EXTENSION glass: interactions so far, per-sample hash seed
+    uint32_t seed;            // EXTENSION glass: per-sample hash seed
+    __device__ __forceinline__ uint32_t aoIdx() const { return xs & 255u; }
+    __device__ __forceinline__ uint32_t aoOpen() const { return (xs >> 8) & 255u; }
+    __device__ __forceinline__ uint32_t bounce() const { return (xs >> 16) & 255u; }
+    __device__ __forceinline__ bool inside() const { return (xs >> 31) != 0u; }
 };
 
 __device__ __forceinline__ void write_rgb(float* __restrict__ out, uint32_t idx, f3 c) {
@@ -1230,14 +1252,21 @@ __device__ __forceinline__ void write_ray(float* o, f3 origin, f3 dir, float len
 // Only for rays whose remaining march stays where float32 cannot overflow (Length < 1e9, |dir| < 1e6, distance from the sphere < 1e15): there
 // every skipped evaluation is finite, so no NaN flag (SdfForm.fs: a NaN distance never terminates; flagged by the kernel and the oracle) is lost.
 // The line is not what the reference evaluates: it accumulates the origin in float32 step by step (Ray.fs:9-13).  escR carries a padding for that
-// drift, proved sufficient (scene.cpp "drift of the marched points") for epsilon >= 0, |dir| >= 1/2 and a start within sqrt(escRho2) of the centre;
-// other rays (a point light's shadow ray has |dir| = 1 / distance, SdfLight.fs:28) simply march on and are asked again at their next step.
+// drift, proved sufficient (scene.cpp "drift of the marched points") for epsilon >= 0 and either of two kinds of ray:
+//   long rays   |dir| >= 1/2 and a start within sqrt(escRho2) of the centre (primary rays, directional shadow rays);
+//   short rays  of any |dir| whose whole remaining march stays within 2.5 escR of the centre and has Length <= 10 escR: every step is >= g, so there are at
+//               most Length / g + 1 <= 20 Rp / padDrift + 1 of them, each of error <= e(2.5 Rp) — the "near" budget of that bound.  (A point light's shadow
+//               ray has |dir| = 1 / distance and Length = distance, SdfLight.fs:28-30: it travels one unit.)  2 (|w|^2 + |dir|^2 Length^2) >= (|w| + |dir| Length)^2.
+// Any other ray simply marches on and is asked again at its next step.
 __device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o, const f3 dir, float eps, float len) {
     if (!(S.escR >= 0.0f) || !(len < 1e9f) || !(eps >= 0.0f)) return false;
     const f3 w = o - mk3(S.escC[0], S.escC[1], S.escC[2]);
     const float re = S.escR + eps;
     const float ww = ft_dot(w, w), cc = ww - re * re, tol = 4e-6f * ww, dd = ft_dot(dir, dir);
-    if (!(cc > tol) || !(ww <= S.escRho2) || !(dd < 1e12f) || !(dd >= 0.25f)) return false;   // inside, too close to tell, or outside what the drift bound covers
+    if (!(cc > tol) || !(dd < 1e12f)) return false;                    // inside, or too close to tell
+    const bool longRay = dd >= 0.25f && ww <= S.escRho2;
+    const bool shortRay = len <= 9.9f * S.escR && 2.0f * (ww + dd * (len * len)) <= 6.2f * (S.escR * S.escR);
+    if (!longRay && !shortRay) return false;                           // outside what the drift bound covers
     const float b = ft_dot(w, dir);
     if (b >= 0.0f) return true;
     return cc * dd - b * b > tol * dd;
@@ -1252,7 +1281,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
         if (s.phase == PH_MARCH) {
             // SdfForm.fs:94 -> SdfScene.fs:10; or every further step is known to miss (EXTENSION glass: a path inside a body marches on
             // -Distance, which is below epsilon everywhere outside the support sphere — the shortcut is for paths outside bodies only)
-            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {
+            if (s.len <= 0.0f || ((!EXT || !s.inside()) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {
                 if (EXT && a.mode >= 2u) write_try_trace_miss(a, s);   // ValueNone of the tryTrace entries
                 else emit<EXT>(a, s, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));
                 s.phase = PH_IDLE;
@@ -1260,25 +1289,25 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             return;
         }
         if (EXT && s.phase == PH_AO) {                                 // EXTENSION
-            if (s.len <= 0.0f) { s.aoOpen += 1; s.aoIdx += 1; s.phase = PH_AONEXT; continue; }
+            if (s.len <= 0.0f) { s.xs += 0x101u; s.phase = PH_AONEXT; continue; }       // unoccluded: count + 1, next ray
             return;
         }
         if (EXT && s.phase == PH_AONEXT) {                             // EXTENSION
-            if (s.aoIdx >= a.aoSamples) {
-                const float f = (float)s.aoOpen / (float)a.aoSamples;
+            if (s.aoIdx() >= a.aoSamples) {
+                const float f = (float)s.aoOpen() / (float)a.aoSamples;
                 sh_set3(FT_SH_LACC, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]) * f);
                 s.lidx = 0; s.phase = PH_LIGHTS;
                 continue;
             }
-            const f3 dir = ft_normalize(sh_get3(FT_SH_NRM) + mk3(FT_AO_DIRS[s.aoIdx][0], FT_AO_DIRS[s.aoIdx][1], FT_AO_DIRS[s.aoIdx][2]));
+            const f3 dir = ft_normalize(sh_get3(FT_SH_NRM) + mk3(FT_AO_DIRS[s.aoIdx()][0], FT_AO_DIRS[s.aoIdx()][1], FT_AO_DIRS[s.aoIdx()][2]));
             ft_count(FT_C_EXT);
-            if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.aoOpen += 1; s.aoIdx += 1; continue; }
+            if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.xs += 0x101u; continue; }
             s.o = sh_get3(FT_SH_HP); s.dir = dir; s.len = a.aoRadius; s.steps = 0;
             s.phase = PH_AO;
             continue;
         }
         if (s.phase == PH_SHADOW) {
-            if (s.len <= 0.0f || ((!EXT || s.sign > 0.0f) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {   // shadow ray missed (or can only miss): light arrives
+            if (s.len <= 0.0f || ((!EXT || !s.inside()) && ft_never_enters(a.S, s.o, s.dir, s.eps, s.len))) {   // shadow ray missed (or can only miss): light arrives
                 const FtLight L = ld_light(as_const(a.S.lights) + s.lidx);                 // the light this shadow ray was cast for (PH_LIGHTS below)
                 const f3 lv = mk3(L.v[0], L.v[1], L.v[2]), hp = sh_get3(FT_SH_HP);
                 f3 lint = mk3(L.color[0], L.color[1], L.color[2]), ldir = lv;             // SdfLight.fs:9, :16
@@ -1357,7 +1386,7 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
             s.seed = x * 0x9E3779B1u + y * 0x85EBCA77u + smp * 0xC2B2AE3Du;
         }
     }
-    if (EXT) { s.sign = 1.0f; s.bounce = 0; }
+    if (EXT) s.xs &= 0xffffu;                                          // outside, no interaction yet
     s.steps = 0; ft_count(FT_C_PRIMARY);
     s.phase = PH_MARCH;
     settle<EXT>(a, s);
@@ -1371,11 +1400,11 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
     const bool glass = mx[0] != 0.0f;
     const f3 black = mk3(0.0f, 0.0f, 0.0f);
     if (!glass) {
-        if (s.sign < 0.0f) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; }     // diffuse seen from inside: absorbed
+        if (s.inside()) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; }       // diffuse seen from inside: absorbed
         return;
     }
     const f3 N = sh_get3(FT_SH_NRM), D = s.dir, hp = sh_get3(FT_SH_HP);
-    if (s.bounce >= a.maxBounces || N.x != N.x || N.y != N.y || N.z != N.z) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; return; }
+    if (s.bounce() >= a.maxBounces || N.x != N.x || N.y != N.y || N.z != N.z) { write_rgb(a.out, s.outIdx, black); s.phase = PH_IDLE; return; }
     float cosi = -ft_dot(N, D);
     if (!(cosi > 0.0f)) cosi = 0.0f;
     float n = mx[1];
@@ -1383,7 +1412,7 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
         const uint32_t smp = s.job / a.jobsPerPlane;
         n = mx[1] + mx[2] * a.spec[smp % a.spectral][3];
     }
-    const float n1 = s.sign > 0.0f ? 1.0f : n, n2 = s.sign > 0.0f ? n : 1.0f;
+    const float n1 = !s.inside() ? 1.0f : n, n2 = !s.inside() ? n : 1.0f;
     const float eta = n1 / n2;                                         // Light.fs:36
     const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
     bool reflect = true;
@@ -1394,7 +1423,7 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
         { const float p = n2 * cosi, q = n1 * cost, x = (p - q) / (p + q); rs = x * x; }   // Light.fs:41-45
         { const float p = n1 * cosi, q = n2 * cost, x = (p - q) / (p + q); rp = x * x; }   // Light.fs:47-51
         const float reflectance = 0.5f * (rs + rp);                    // Light.fs:53
-        const float u = (float)(ft_glass_hash(s.seed, s.bounce) >> 8) * (1.0f / 16777216.0f);
+        const float u = (float)(ft_glass_hash(s.seed, s.bounce()) >> 8) * (1.0f / 16777216.0f);
         reflect = u < reflectance;
     }
     ft_count(FT_C_EXT);
@@ -1404,10 +1433,10 @@ __device__ __forceinline__ void glass_bounce(const FtRenderArgs& a, LaneState& s
     } else {
         s.dir = ft_normalize(D * eta + N * (eta * cosi - cost));       // Light.fs:58
         s.o = hp - N * (4.0f * s.eps);
-        s.sign = -s.sign;
-        if (s.sign < 0.0f) { cfp t = as_const(a.S.materials) + 3u * s.leaf; s.thr = s.thr * mk3(t[0], t[1], t[2]); }
+        s.xs ^= 0x80000000u;
+        if (s.inside()) { cfp t = as_const(a.S.materials) + 3u * s.leaf; s.thr = s.thr * mk3(t[0], t[1], t[2]); }
     }
-    s.bounce += 1;
+    s.xs += 0x10000u;
     s.len = a.length; s.steps = 0;
     s.phase = PH_MARCH;
 }
@@ -1435,7 +1464,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
 #endif
     __syncthreads();
 
-    float* coopRow = ft_lds + ft_coop_lds_offset(a.S, MATH != 0) + (tid >> 6) * FT_CULL_ROW;   // lean kernel: this wave's row (latency mode / culled children)
+    // this wave's row (lean kernel: latency mode and culled children; other kernels: culled children of the scene's cull site) — a wave-uniform address
+    float* coopRow = ft_lds + ft_coop_lds_offset(a.S, MATH != 0) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * FT_CULL_ROW;
     uint32_t cullSkipped = 0, cullTotal = 0;                           // (child, ray) pairs the culling pass dropped / looked at (wave-uniform sums)
     uint32_t chunkNext = 0, chunkEnd = 0;                              // wave-uniform
     uint32_t waveEvals = 0;                                            // evaluation rounds of this wave (lane-utilisation statistic)
@@ -1446,8 +1476,8 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     s.phase = PH_IDLE; s.job = 0; s.steps = 0; s.lidx = 0; s.leaf = 0; s.outIdx = 0;
     s.o = s.dir = mk3(0, 0, 0);
     s.len = 0; s.eps = 0;
-    s.aoIdx = s.aoOpen = 0;
-    s.sign = 1.0f; s.thr = splat3(1.0f); s.bounce = 0; s.seed = 0;
+    s.xs = 0;
+    s.thr = splat3(1.0f); s.seed = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk ------------------------------------------
@@ -1530,10 +1560,11 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         }
         // ---- lean kernel: drop the children whose terms no ray of this wave can feel this round ("Exact child culling") ----
         uint32_t cullN = FT_CULL_NONE;
-        if (VARIANT == 1 && a.cull != 0u && !coop && am != 0ull) {
+        if (VARIANT != 3 && a.cull != 0u && !coop && am != 0ull) {
             cullN = ft_cull_children(a.S, query_point(), active, am, ldsC, coopRow);
             if (cullN != FT_CULL_NONE) {
-                const uint32_t looked = as_const(a.S.instr)->count < FT_CULL_MAX ? as_const(a.S.instr)->count : FT_CULL_MAX;
+                const uint32_t cnt = (as_const(a.S.instr) + a.S.cullPc)->count;
+                const uint32_t looked = cnt < FT_CULL_MAX ? cnt : FT_CULL_MAX;
                 cullTotal += looked * (uint32_t)__popcll(am) >> 6; cullSkipped += (looked - cullN) * (uint32_t)__popcll(am) >> 6;   // in units of 64 pairs
             }
         }
@@ -1546,10 +1577,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 if (VARIANT == 1) ft_eval_smooth_spheres<MATH>(a.S, q, ldsC, d, leaf, coopRow, cullN);
                 else if (VARIANT == 3) ft_eval_carved<K>(a.S, a.carve, q, d, leaf, a.lazy == 0u ? __builtin_inff() : s.eps);
                 else ft_eval<VARIANT == 2, MATH>(a.S, q, sd, sl, ldsC, d, leaf,          // lazy unions: off (+inf) inside a glass body, whose exit is a "hit" at large values
-                                                  (EXT && s.sign < 0.0f) || a.lazy == 0u ? __builtin_inff() : s.eps);
+                                                  (EXT && s.inside()) || a.lazy == 0u ? __builtin_inff() : s.eps, coopRow, cullN);
             }
             FT_UDBG_T1(5, tEval); FT_UDBG_WAVE(6);
-            if (EXT) d *= s.sign;                                      // EXTENSION glass: inside, march on -Distance
+            if (EXT) d = __uint_as_float(__float_as_uint(d) ^ (s.xs & 0x80000000u));   // EXTENSION glass: inside, march on -Distance
 
             switch (s.phase) {
             case PH_MARCH:
@@ -1568,7 +1599,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                         }
                     }
                     else if (s.phase == PH_SHADOW) { ft_count(FT_C_HITS); s.lidx += 1; s.phase = PH_LIGHTS; }   // shadowed (SdfLight.fs:20)
-                    else { s.aoIdx += 1; s.phase = PH_AONEXT; }        // EXTENSION: occluded
+                    else { s.xs += 1u; s.phase = PH_AONEXT; }          // EXTENSION: occluded
                 } else {
                     s.o = s.o + s.dir * d;                             // Ray.move (Ray.fs:9-13)
                     s.len = s.len - d;
@@ -1589,7 +1620,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 sh_set3(FT_SH_LACC, mk3(a.S.bg[0], a.S.bg[1], a.S.bg[2]));     // SdfScene.fs:12
                 s.lidx = 0;
                 s.phase = PH_LIGHTS;
-                if (EXT && a.aoSamples != 0u) { s.aoIdx = 0; s.aoOpen = 0; s.phase = PH_AONEXT; }   // EXTENSION
+                if (EXT && a.aoSamples != 0u) { s.xs &= 0xffff0000u; s.phase = PH_AONEXT; }   // EXTENSION: AO counters to 0
                 if (EXT && a.maxBounces != 0u) glass_bounce(a, s);     // EXTENSION
                 if (EXT && a.mode == 3u) {                             // SdfObject.tryTrace result (SdfObject.fs:72-77)
                     float* o = a.out + 16ull * s.outIdx;
@@ -1662,12 +1693,13 @@ extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_CALLS_OCC ft_trace_ker
 extern "C" __global__ void __launch_bounds__(FT_BLOCK) ft_trace_kernel_calls_ext(const FtRenderArgs a) { ft_trace_body<2, true>(a); }
 // scenes that are one grid union of plain primitives of kind K with at most two intersect / subtract steps behind it (ft_device.h "Carved union":
 // the reference's own Program.fs scene is the torus one).  No exponential anywhere: no *_libm twins; EXTENSION launches take ft_trace_kernel_ext.
-// Resident waves per SIMD asked of the register allocator: 7 (72 VGPRs) where the inlined primitive fits without spills (capsules: 6, 75 registers), 5 (96) for triangles and
-// the type switch of mixed kinds (91 registers; at 6 and more they spill into the walk).  Measured: profiles/r04_carved_variants.txt.
+// Resident waves per SIMD asked of the register allocator: 6 (80 VGPRs) where the inlined primitive fits without spills — 7 (72) measured the same
+// and leaves no register to spare — and 5 (96) for triangles and the type switch of mixed kinds (93 registers; at 6 and more they spill into the walk).
+// Measured: profiles/r04_carved_variants.txt.
 #define FT_CARVE_KERNEL(name, kind, waves) extern "C" __global__ void __launch_bounds__(FT_BLOCK) FT_OCC(waves) name(const FtRenderArgs a) { ft_trace_body<3, false, 0, (int)(kind)>(a); }
-FT_CARVE_KERNEL(ft_trace_kernel_carved_spheres, FT_PR_SPHERE, 7)
+FT_CARVE_KERNEL(ft_trace_kernel_carved_spheres, FT_PR_SPHERE, 6)
 FT_CARVE_KERNEL(ft_trace_kernel_carved_capsules, FT_PR_CAPSULE, 6)
-FT_CARVE_KERNEL(ft_trace_kernel_carved_tori, FT_PR_TORUS, 7)
+FT_CARVE_KERNEL(ft_trace_kernel_carved_tori, FT_PR_TORUS, 6)
 FT_CARVE_KERNEL(ft_trace_kernel_carved_triangles, FT_PR_TRIANGLE, 5)
 FT_CARVE_KERNEL(ft_trace_kernel_carved_mixed, FT_CARVE_MIXED, 5)
 static const void* ft_carved_kernel(unsigned kind) {

@@ -819,6 +819,19 @@ static bool carvedShape(FlatScene& out) {
     return true;
 }
 
+// Every constant of every primitive under `h` is finite.  A capsule of length 0 (dirInv = 0 / 0), a collinear triangle or a torus with a zero normal
+// evaluates to NaN everywhere, and MathF.Max / Min carry that NaN to the scene's value wherever the form sits in the tree — also where supportOf
+// never looks (the subtrahend of a subtract, the later children of an intersect).  The reference's march never ends on a NaN and both sides flag it:
+// a ray ended early would not, so such a scene gets no support sphere.
+static bool finiteTree(const Builder& b, int h, int depth = 0) {
+    if (depth > 64 || !b.okForm(h)) return false;
+    const HostForm& f = b.forms[h];
+    if (f.isPrim()) { for (float v : f.params) if (!std::isfinite(v)) return false; return true; }
+    if (f.kind == HostForm::SMOOTH && !std::isfinite(f.strength)) return false;
+    for (int k : f.kids) if (!finiteTree(b, k, depth + 1)) return false;
+    return true;
+}
+
 bool flatten(const Builder& b, int object, const float bg[3], const int* lights, int nLights, FlatScene& out, std::string& err) {
     if (!b.okObject(object)) { err = "invalid object handle"; return false; }
     out = FlatScene{};
@@ -846,7 +859,7 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     //                 < 34 * 3 * 2^-23 rho + e-terms in |c|inf that stay below rho / 100, against a margin rho - Rp - epsilon' that has grown to >= rho / 2.
     //     Near and approach together stay <= padDrift / 2: the supposition holds step after step, every evaluated point keeps its distance, no step can be a hit.
     Support sup;
-    if (supportOf(b, b.objects[object].form, sup) && sup.r < 1e15 && std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]) < 1e15) {
+    if (finiteTree(b, b.objects[object].form) && supportOf(b, b.objects[object].form, sup) && sup.r < 1e15 && std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]) < 1e15) {
         out.escC[0] = (float)sup.c[0]; out.escC[1] = (float)sup.c[1]; out.escC[2] = (float)sup.c[2];
         const double cInf = std::max(std::fabs(sup.c[0]), std::max(std::fabs(sup.c[1]), std::fabs(sup.c[2])));
         const double padEval = sup.r * 0.001 + 0.01 + 1e-3 * (std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]));
@@ -872,6 +885,11 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
         else lean = false;
     }
     out.fastPath = lean ? 1u : (fl.calls.empty() ? 0u : 2u);     // kernel variant (ft_launch_trace)
+    // the child-culling pass serves ONE sphere run of the main program: the longest staged fast one with at least 32 children and a positive strength
+    for (uint32_t pc = 0, best = 0; pc < out.nMainInstr; ++pc) {
+        const FtInstr& in = out.instr[pc];
+        if (in.op == FT_OP_SMOOTH_RUN && (in.flags & FT_FLAG_FAST) && in.count >= 32u && in.count > best && in.f0 < 0.0f && in.data + 4u * in.count <= out.nStage) { best = in.count; out.cullPc = pc; }
+    }
     if (out.fastPath == 0u && carvedShape(out)) out.fastPath = 3u;
     for (int i = 0; i < nLights; ++i) {
         if (lights[i] < 0 || (size_t)lights[i] >= b.lights.size()) { err = "invalid light handle"; return false; }

@@ -103,6 +103,7 @@ struct FlatScene {                                            // host copy of ev
     uint32_t fastQ = 0;                                       // see FtSceneDev::fastQ
     float escC[3] = {0, 0, 0}, escR = -1.0f;                  // see FtSceneDev::escR (support sphere of the scene; -1: none)
     float escRho2 = 0.0f;                                     // see FtSceneDev::escRho2
+    uint32_t cullPc = 0xffffffffu;                            // see FtSceneDev::cullPc
     uint32_t fastPath = 0;
     FtCarve carve{};                                          // fastPath == 3 (ft_device.h "Carved union"); the two pointers are set at upload
     std::vector<FtItemRec> itemsT;                            // fastPath == 3: candidate lists with a terminator per cell

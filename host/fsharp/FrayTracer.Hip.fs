@@ -58,7 +58,7 @@ module Native =
 
     /// FT_ABI_VERSION this file was written against (include/fraytracer_hip.h); checked when the context is created
     [<Literal>]
-    let AbiVersion = 4
+    let AbiVersion = 5
 
     [<DllImport(Lib)>] extern int ft_abi_version()
     [<DllImport(Lib)>] extern nativeint ft_build_info()
@@ -113,7 +113,8 @@ module Native =
     /// FT_OPT_CULL (9), FT_OPT_ESCAPE (10), FT_OPT_LAZY_UNION (11), all on by default: the smooth-union kernel skips children whose terms cannot change
     /// the running float32 sum, a ray that can no longer come within epsilon of the scene's support sphere ends as a miss at once, and a union under
     /// an intersect stops at Items.[0] where the intersect's next child already decides.  All are exact — the frame and the ray / hit counters do
-    /// not change; `false` makes the GPU do every evaluation, child and candidate the CPU path does.
+    /// not change; `false` makes the GPU do every evaluation, child and candidate the CPU path does.  (FT_OPT_CARVED (12) only picks the kernel: the
+    /// specialised one for a union of primitives with at most two intersect / subtract steps behind it — Program.fs's own scene — or the interpreter.)
     let setExactShortcuts (on : bool) =
         for opt in [ 9; 10; 11 ] do
             if ft_ctx_set_option (ctx.Value, opt, (if on then 1 else 0)) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FT_ABI_VERSION 4
+#define FT_ABI_VERSION 5
 
 typedef enum ft_status {
     FT_OK = 0,
@@ -254,7 +254,9 @@ int ft_render_multi(ft_ctx* const* ctxs, const ft_scene* const* scenes, int32_t 
 /* ---- introspection of the flattened scene (tests; not needed by a caller) ---------------- */
 typedef struct ft_scene_info {
     int32_t n_instr, n_slots, n_consts, n_grids, n_children, n_cells, n_items, n_lights, n_materials;
-    int32_t fast_path;            /* which specialised evaluator the scene selected (0 = general) */
+    int32_t fast_path;            /* which specialised evaluator the scene selected: 0 general interpreter, 1 smooth union of spheres, 2 general with
+                                   * on-demand sub-programs, 3 carved union (one union of primitives + at most two intersect / subtract steps) */
+    int32_t cull_pc;              /* instruction of the program whose sphere run the child-culling pass serves; -1: none */
 } ft_scene_info;
 int ft_scene_info_get(const ft_scene*, ft_scene_info* out);
 /* grid g: info = aabbMin[3], cellSizeInv[3]; counts[3]; arrays sized from ft_scene_info /

@@ -35,7 +35,7 @@ def test_blittable_layouts_match_the_reference_records():
     assert C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Boundary) == 16 and C.sizeof(_lib.CameraS) == 48
     assert C.sizeof(_lib.Sphere) == 16 and C.sizeof(_lib.Capsule) == 28 and C.sizeof(_lib.Torus) == 32 and C.sizeof(_lib.Triangle) == 40
     assert C.sizeof(_lib.RenderParams) == 56 and C.sizeof(_lib.Stats) == 80
-    assert _lib.lib.ft_abi_version() == 4
+    assert _lib.lib.ft_abi_version() == 5
 
 
 def test_the_library_is_built_in_tree_and_is_not_the_oracle():
@@ -134,7 +134,7 @@ def test_header_is_plain_c99_with_the_reference_layouts(tmp_path):
         got[(kind, name)] = int(val)
     want_sizes = {"ft_vec3": 12, "ft_ray": 32, "ft_boundary": 16, "ft_form_trace_result": 40, "ft_object_trace_result": 64,
                   "ft_sphere": 16, "ft_capsule": 28, "ft_torus": 32, "ft_triangle": 40, "ft_box": 24, "ft_camera": 48,
-                  "ft_render_params": 56, "ft_stats": 80, "ft_scene_info": 40, "ft_handle": 4, "ft_tonemap_params": 16}
+                  "ft_render_params": 56, "ft_stats": 80, "ft_scene_info": 44, "ft_handle": 4, "ft_tonemap_params": 16}
     for k, v in want_sizes.items():
         assert got[("sizeof", k)] == v, (k, got[("sizeof", k)], v)
     want_offsets = {"ft_ray.direction": 12, "ft_ray.length": 24, "ft_ray.epsilon": 28, "ft_boundary.radius": 12,

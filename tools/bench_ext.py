@@ -34,4 +34,5 @@ for name, scene, n, kw in (("EXT C2: union of 16 spheres + 16 boxes, diffuse + 8
     ms = st["kernel_ms"] / reps
     print(json.dumps({"scene": name, "kernel_ms": round(ms, 3), "Mrays/s": round(rays / ms / 1e3, 1), "primary": st["rays_primary"] // reps,
                       "shadow": st["rays_shadow"] // reps, "ext_rays": st["rays_ext"] // reps,
-                      "lane_util": round(st["sdf_evals"] / (64.0 * st["wave_evals"]), 4)}), flush=True)
+                      "lane_util": round(st["sdf_evals"] / (64.0 * st["wave_evals"]), 4), "culled_fraction": round(st["culled_fraction"], 4),
+                      "cull_site": ds.info().get("cull_pc")}), flush=True)
