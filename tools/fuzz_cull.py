@@ -3,7 +3,9 @@
 spreads over two decades) seen by random cameras — far away, close by, inside the cloud — on wide, low frames (a fine pixel pitch keeps the rays of a
 wave together, which is when children are dropped).  HIP path against the CPU oracle, float for float and counter for counter, with the pass on; the
 share of dropped (child, ray) pairs is reported.  `wide`: scene extents from 0.1 to 3000 and strengths from 0.03 to 100 (the slack of the pass's bounds is absolute: large coordinates and weak
-unions are where it is smallest relative to the arithmetic's own rounding).  Usage: python tools/fuzz_cull.py [first_seed] [count] [wide]"""
+unions are where it is smallest relative to the arithmetic's own rounding).  `nested` (round 4): the smooth union sits inside a general scene — in a union beside
+other objects, under an intersect or a subtract, behind children of another kind (its sphere run then continues an accumulator) — so the pass runs in the
+general kernels (FtSceneDev.cullPc).  Usage: python tools/fuzz_cull.py [first_seed] [count] [wide|nested]"""
 import json
 import os
 import sys
@@ -20,6 +22,7 @@ from oracle import binding as ob
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+nested = len(sys.argv) > 3 and sys.argv[3] == "nested"
 dev = ft.Device(0)
 from _opts import apply_env_options
 applied = apply_env_options(dev)
@@ -39,7 +42,16 @@ for seed in range(first, first + count):
     lights = [SdfLight.directional(tuple(float(v) for v in rng.normal(size=3)), (0.5, 0.5, 0.5))]
     if rng.random() < 0.4:
         lights.append(SdfLight.point(tuple(float(v) for v in rng.normal(size=3) * spread), (3.0, 2.0, 1.0)))
-    scene = SdfScene(SdfObject.create(SdfMaterial.createSolid((0.9, 0.6, 0.3)), SdfForm.unionSmooth(strength, forms)), syn.BACKGROUND, lights)
+    root = SdfObject.create(SdfMaterial.createSolid((0.9, 0.6, 0.3)), SdfForm.unionSmooth(strength, forms))
+    if nested:
+        P, k = SdfForm.Primitive, int(rng.integers(0, 4))
+        pt = lambda s=0.5: tuple(float(v) for v in rng.normal(size=3) * spread * s)
+        m2 = SdfMaterial.createSolid((0.2, 0.5, 0.9))
+        if k == 0: root = SdfObject.union([root, SdfObject.create(m2, P.torus(pt(), (0.0, 1.0, 0.0), spread * 0.4, spread * 0.05)), SdfObject.create(m2, P.capsule(pt(), pt(), spread * 0.08))])
+        elif k == 1: root = SdfObject.intersect(root, [P.sphere(pt(0.1), spread * float(rng.uniform(0.5, 1.2)))])
+        elif k == 2: root = SdfObject.subtract(root, P.sphere(pt(0.4), spread * float(rng.uniform(0.2, 0.6))))
+        else: root = SdfObject.create(SdfMaterial.createSolid((0.9, 0.6, 0.3)), SdfForm.unionSmooth(strength, [P.capsule(pt(), pt(), spread * 0.05), P.torus(pt(), (1.0, 0.0, 0.0), spread * 0.3, spread * 0.04)] + forms))
+    scene = SdfScene(root, syn.BACKGROUND, lights)
     dist = spread * float(10.0 ** rng.uniform(-0.7, 0.8))          # inside the cloud ... far outside
     pos = rng.normal(size=3); pos = pos / np.linalg.norm(pos) * dist
     cam = Camera.lookAt(Position=tuple(float(v) for v in pos), LookAt=tuple(float(v) for v in rng.normal(size=3) * spread * 0.2), Up=(0.0, 1.0, 0.0),
