@@ -225,7 +225,7 @@ size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false, 
     return floats * 4;
 }
 // Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
-constexpr int FT_TAIL_K_LEAN = 32, FT_TAIL_K_GENERAL = 2;
+constexpr int FT_TAIL_K_LEAN = 32, FT_TAIL_K_GENERAL = 2, FT_TAIL_K_CARVED = 1;      // carved: 1.26 ms at 0 / 1 against 1.29 at 2 on the 1000^2 Program.fs frame (profiles/r04_carved_variants.txt)
 // does this launch take the glibc build of the kernels?
 bool libmLaunch(const ft_ctx* c, const ft_scene* s) { return c->optMath != FT_MATH_FIXED && s->usesExpLog; }
 
@@ -295,7 +295,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     // glass config 39.1 / 31.5 / 27.3, and even the VALU-bound C3 kernel 61.0 / 66.5 / 60.3: rays that start together stay in
     // step (march, the four normal probes, shadow rays), so a wave's lanes share lookup cells, list positions and branches.
     a.refillMin = (uint32_t)c->optRefillMin;               // 64 unless FT_OPT_REFILL_MIN says otherwise (experiments)
-    a.tailK = (uint32_t)(c->optTailK >= 0 ? c->optTailK : (s->dev.fastPath == 1u ? FT_TAIL_K_LEAN : FT_TAIL_K_GENERAL));
+    a.tailK = (uint32_t)(c->optTailK >= 0 ? c->optTailK : (variant == 1u ? FT_TAIL_K_LEAN : variant == 3u ? FT_TAIL_K_CARVED : FT_TAIL_K_GENERAL));
     // guided hand-out of the last jobs (kernels.hip refill): one half tile, then one quarter tile per resident wave — only where the latency
     // mode makes a part-filled wave cheap (lean kernel, tailK >= 32) and only for the reference's sampling (tile-major job order)
     a.shrink1 = a.shrink2 = a.nJobs;

@@ -118,6 +118,8 @@ struct FtSceneDev {             // passed by value as kernel argument
 #define FT_CARVE_TAIL 2
 #define FT_CARVE_MIXED 7u       // FtCarve.kind when the union's children are not all of one primitive kind
 struct FtCarveOp { uint32_t op, type, data, bound; };   // op: FT_OP_ISECT_RUN (one child: consts[data], boundary consts[bound]) or FT_OP_SUBTRACT (consts[data])
+#define FT_CARVE_FAST_SPHERE 0x100u   // FtCarveOp.type flag: a sphere whose parameters admit the clamped fast root (|c| <= 1e4, 2^-20 <= r <= 1e4, like a union candidate's)
+                                      // and, under an intersect, whose pruning boundary is the sphere itself bit for bit: ONE root serves distance and bound
 struct FtCarve {
     uint32_t kind;              // FtPrim of every child of the union, or FT_CARVE_MIXED
     uint32_t nTail;

@@ -1141,6 +1141,7 @@ __device__ __forceinline__ void carve_walk(const FtSceneDev& S, const FtCarve& C
 template <int K, bool COOP = false>
 __device__ __forceinline__ void ft_eval_carved(const FtSceneDev& S, const FtCarve& CV, const f3 p, float& outD, uint32_t& outLeaf, float epsHit) {
     cfp consts = as_const(S.consts);
+    const bool pointOk = fast_point_ok(p);                             // wave-uniform: p finite and |p|inf < 20000 in every lane that evaluates
     // the tail's primitives first: wave-uniform kinds and constants
     float t[FT_CARVE_TAIL], b[FT_CARVE_TAIL];
     float m = -__builtin_inff();                                       // the tail applied to -inf, as a value
@@ -1149,11 +1150,17 @@ __device__ __forceinline__ void ft_eval_carved(const FtSceneDev& S, const FtCarv
     for (int k = 0; k < FT_CARVE_TAIL; ++k) {
         t[k] = 0.0f; b[k] = 0.0f;
         if ((uint32_t)k < CV.nTail) {
-            const uint32_t op = CV.tail[k].op;
-            t[k] = prim_eval(CV.tail[k].type, consts + CV.tail[k].data, p);
+            const uint32_t op = CV.tail[k].op, type = CV.tail[k].type;
+            if (pointOk && (type & FT_CARVE_FAST_SPHERE)) {            // one clamped fast root (bit-identical to sqrtf here: ft_sq) for the distance and the bound
+                cfp c = consts + CV.tail[k].data;
+                const float dist = ft_dist<true>(ld3(c), p);
+                t[k] = dist - c[3];                                    // SdfForm.fs:129
+                b[k] = dist + c[3];                                    // SdfForm.fs:62 getMaxDistance of the sphere's own boundary (SdfForm.fs:131-135)
+            } else {
+                t[k] = prim_eval(type & 15u, consts + CV.tail[k].data, p);
+                if (op == FT_OP_ISECT_RUN) { cfp bd = consts + CV.tail[k].bound; b[k] = ft_distance(ld3(bd), p) + bd[3]; }   // SdfForm.fs:62
+            }
             if (op == FT_OP_ISECT_RUN) {
-                cfp bd = consts + CV.tail[k].bound;
-                b[k] = ft_distance(ld3(bd), p) + bd[3];                // SdfForm.fs:62 getMaxDistance
                 lazyOk = lazyOk && t[k] <= b[k];
                 m = ft_vmax(m, t[k]);
             } else { lazyOk = lazyOk && t[k] == t[k]; m = ft_vmax(m, -t[k]); }
@@ -1161,7 +1168,7 @@ __device__ __forceinline__ void ft_eval_carved(const FtSceneDev& S, const FtCarv
     }
     const float cap = (lazyOk && m >= epsHit && m > 0.0f) ? m : -__builtin_inff();      // epsHit = +inf: never
     float v; uint32_t leaf;
-    const bool fastOk = S.fastQ != 0u && fast_point_ok(p);
+    const bool fastOk = S.fastQ != 0u && pointOk;
     if (COOP) {
         // latency mode (see "Latency (tail) mode"): one query point, the same in all 64 lanes; the cell's candidates are spread over the lanes and the
         // reference's decisions replayed in list order (eval_union_coop: the walk runs to its end, which the early exit above never changes)

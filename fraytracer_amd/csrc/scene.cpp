@@ -783,6 +783,10 @@ static bool carvedShape(FlatScene& out) {
     if (kind == FT_PR_SLOT) return false;
     FtCarve cv{};
     cv.kind = kind;
+    auto fastSphere = [](const float* q) {                              // the bounds of noteUnionChild for a sphere (c.xyz, r)
+        for (int k = 0; k < 3; ++k) if (!(std::isfinite(q[k]) && fabsf(q[k]) <= 1.0e4f)) return false;
+        return std::isfinite(q[3]) && q[3] >= 0x1p-20f && q[3] <= 1.0e4f;
+    };
     auto strideOf = [](uint32_t t) { return t == FT_PR_SPHERE ? FT_STRIDE_SPHERE : t == FT_PR_CAPSULE ? FT_STRIDE_CAPSULE : t == FT_PR_TORUS ? FT_STRIDE_TORUS
                                           : t == FT_PR_TRIANGLE ? FT_STRIDE_TRIANGLE : FT_STRIDE_BOX; };
     for (size_t k = 1; k < out.instr.size(); ++k) {
@@ -790,12 +794,16 @@ static bool carvedShape(FlatScene& out) {
         if (in.op == FT_OP_ISECT_RUN && in.dst == 0) {
             for (uint32_t j = 0; j < in.count; ++j) {
                 if (cv.nTail == FT_CARVE_TAIL) return false;
-                cv.tail[cv.nTail++] = FtCarveOp{FT_OP_ISECT_RUN, in.type, in.data + j * (uint32_t)strideOf(in.type), in.aux + 4u * j};
+                FtCarveOp op{FT_OP_ISECT_RUN, in.type, in.data + j * (uint32_t)strideOf(in.type), in.aux + 4u * j};
+                if (in.type == FT_PR_SPHERE && fastSphere(&out.consts[op.data]) && memcmp(&out.consts[op.data], &out.consts[op.bound], 16) == 0) op.type |= FT_CARVE_FAST_SPHERE;
+                cv.tail[cv.nTail++] = op;
             }
         } else if (in.op == FT_OP_PRIM && in.dst == 1 && k + 1 < out.instr.size() && out.instr[k + 1].op == FT_OP_SUBTRACT &&
                    out.instr[k + 1].dst == 0 && out.instr[k + 1].src == 1) {
             if (cv.nTail == FT_CARVE_TAIL) return false;
-            cv.tail[cv.nTail++] = FtCarveOp{FT_OP_SUBTRACT, in.type, in.data, 0u};
+            FtCarveOp op{FT_OP_SUBTRACT, in.type, in.data, 0u};
+            if (in.type == FT_PR_SPHERE && fastSphere(&out.consts[op.data])) op.type |= FT_CARVE_FAST_SPHERE;
+            cv.tail[cv.nTail++] = op;
             ++k;
         } else return false;
     }

@@ -391,7 +391,7 @@ def test_child_culling_in_the_general_kernels(gpu, oracle):
         for name, obj, kw, must_cull in cases:
             scene = SdfScene(obj, syn.BACKGROUND, syn.program_lights())
             ds, os_ = both(gpu, oracle, scene)
-            assert ds.info()["fast_path"] in (0, 2), name
+            assert ds.info()["fast_path"] in ((0, 2) if not kw else (0, 1, 2)), name        # (the glass blob alone is a lean scene: its EXTENSION build culls too)
             for W, H in ((1536, 16), (96, 64)):
                 want, ocnt = os_.render(EPS, LEN, W, H, cam.as_array(), **kw)
                 for cull in (1, 0):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Kernel time of ONE rank's share of the C3 4096^2 frame when it is split over N ranks (interleaved 16-column
-stripes), on one GPU: shows the tail / launch overhead strong scaling pays.  FT_MAX_BLOCKS_PER_CU caps occupancy."""
+"""Kernel time of ONE rank's share of the C3 frame when it is split over N ranks (interleaved 16-column
+stripes), on one GPU: shows the tail / launch overhead strong scaling pays.  FT_MAX_BLOCKS_PER_CU caps occupancy.
+Usage: python tools/tail_probe.py [size]   (4096 = the metric's config, 8192 = BASELINE.json config 4)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +12,7 @@ dev = ft.Device(0)
 from _opts import apply_env_options
 applied = apply_env_options(dev)
 cam = syn.default_camera()
-W = 4096
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ds = dev.scene(syn.config3(size=W)[0])
 size = ft.ImageSize(W, W)
 out = {}
@@ -25,5 +26,5 @@ for N in (1, 2, 4, 8):
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, buf.data_ptr(), **kw)
     st = ds.collect_stats()
     out[N] = round(st["kernel_ms"] / reps, 3)
-print(json.dumps({"options": applied, "kernel_ms_per_rank_share": out,
+print(json.dumps({"options": applied, "size": W, "build": ft.build_info()["src"], "kernel_ms_per_rank_share": out,
                   "efficiency_vs_N1": {n: round(out[1] / (n * out[n]), 3) for n in out}}))
