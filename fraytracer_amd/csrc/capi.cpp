@@ -216,12 +216,12 @@ int uploadScene(ft_ctx* c, ft_scene* s) {
 // traceLaunch: the lean trace kernel keeps its accumulator in a register and is launched with nSlots = 0 (launchTrace) — 2 KB per workgroup
 // that decide between 6 and 7 resident workgroups per CU; every other user of a lean scene (ft_eval_distance) runs the general interpreter
 // variant: the kernel family of a trace launch (launchTrace: FtSceneDev.fastPath, or 0 where a carved scene takes the general kernel)
-size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false, unsigned variant = 0) {
+size_t ldsBytes(const ft_scene* s, bool libm = false, bool traceLaunch = false, unsigned variant = 0, bool cullRows = true) {
     const size_t nSlots = (traceLaunch && (variant == 1u || variant == 3u)) ? 0 : s->dev.nSlots;       // the lean and the carved kernels keep their values in registers
     size_t floats = (size_t)FT_LDS_HDR_FLOATS + nSlots * FT_BLOCK * 2 + (size_t)s->dev.nStage;
     if (libm) floats = ((floats + 1) & ~(size_t)1) + (size_t)FT_LIBM_TAB_DOUBLES * 2;
     // one row per wave behind everything: the lean kernel's latency mode and culled children; any other trace kernel's culled children where the scene has a cull site
-    if (s->dev.fastPath == 1u || (traceLaunch && variant != 3u && s->dev.cullPc != 0xffffffffu)) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
+    if (s->dev.fastPath == 1u || (cullRows && traceLaunch && variant != 3u && s->dev.cullPc != 0xffffffffu)) floats = ((floats + 3) & ~(size_t)3) + (size_t)FT_COOP_SEG_FLOATS * (FT_BLOCK / 64);
     return floats * 4;
 }
 // Latency-mode thresholds (rays per wave at or below which each ray is evaluated by all 64 lanes; measured)
@@ -262,10 +262,15 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     const bool libm = libmLaunch(c, s);
     // kernel family: a "carved union" scene takes the general kernels for EXTENSION launches and with FT_OPT_CARVED = 0
     const unsigned variant = (s->dev.fastPath == 3u && (a.ext != 0u || !c->optCarved)) ? 0u : s->dev.fastPath;
-    const size_t lds = ldsBytes(s, libm, true, variant);
+    size_t lds = ldsBytes(s, libm, true, variant);
+    bool cullRows = true;
     {   // a scene too large for the workgroup's LDS is refused here, not by a launch failure
         int maxLds = 0;
         HIP_TRY(hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));
+        if (lds > (size_t)maxLds && variant != 1u && s->dev.cullPc != 0xffffffffu) {       // the general kernels' culling rows are optional: without them the pass is off
+            cullRows = false;
+            lds = ldsBytes(s, libm, true, variant, false);
+        }
         if (lds > (size_t)maxLds) return setErr(FT_ERR_UNSUPPORTED, "scene needs " + std::to_string(lds) + " bytes of LDS per workgroup; the device offers " + std::to_string(maxLds));
     }
     HIP_TRY(ft_trace_occupancy(variant, s->carve.kind, a.ext != 0u, libm, lds, &perCU));
@@ -311,7 +316,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.carve = s->carve;
     if (variant == 1u || variant == 3u) a.S.nSlots = 0;    // the lean and carved kernels use no value slots: their LDS layout has none (ldsBytes)
     a.math = libm ? 1u : 0u;
-    a.cull = (s->dev.cullPc != 0xffffffffu && variant != 3u && c->optCull) ? 1u : 0u;
+    a.cull = (s->dev.cullPc != 0xffffffffu && variant != 3u && cullRows && c->optCull) ? 1u : 0u;
     if (!c->optEscape) a.S.escR = -1.0f;
     a.lazy = c->optLazyUnion ? 1u : 0u;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
