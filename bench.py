@@ -571,7 +571,7 @@ def program_fs_block(console, cam, steps, build_src):
     rays = (cst["rays_primary"] + cst["rays_shadow"]) / steps
     achieved = flops_per_eval * evals_ref / kernel_s / 1e12
     achieved_executed = flops_per_eval_executed * evals / kernel_s / 1e12
-    _, prof_src, valu_busy = profile_figures(build_src, "# case: Program.fs scene 4000^2")
+    _, prof_src, valu_busy = profile_figures(build_src, "# case: Program.fs scene 4000")
     return {"workload": f"Program.fs scene, {CW}x{CW}, 1 spp, directional + point light", "value": round(rays / kernel_s / 1e6, 1), "unit": "Mrays/s",
             "kernel_ms": round(kernel_s * 1e3, 3), "kernel": "ft_trace_kernel_carved_tori", "rays_per_frame": int(rays), "sdf_evals_per_frame": int(evals_ref),
             "sdf_evals_executed_per_frame": int(evals), "kernel_ms_with_every_ray_marched_and_every_walk_run_to_its_end": round(console["ref_kernel_ms"], 3),
