@@ -313,9 +313,12 @@ template <int PW> __device__ __forceinline__ float ft_strength_times_diff(float 
 }
 __device__ __forceinline__ int ft_strength_pw(float si) { return si == -2.0f ? 1 : (si == -4.0f ? 2 : (si == -0.5f ? 3 : 0)); }
 
-template <bool NEAR, int PW = 0>
+// CLAMP = false (round 4): the culling pass of this wave and round has established that no ray's point lies within 1e-6 of any child's centre
+// (ft_cull_children: |c - q0| - rho >= 1e-5 |c - q0| + 1e-6 for every child looked at), so every q is >= 1e-12 and the clamp at 2^-96 is a no-op: 25 instructions per child
+template <bool NEAR, int PW = 0, bool CLAMP = true>
 __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict__ ldsC, uint32_t count, float si_, f3 p, float sum) {
     static_assert(NEAR || PW == 0, "output modifiers exist only in the near loop's mode region");
+    static_assert(CLAMP || NEAR, "the clamp-free form exists for the near loop only");
     float si = si_;
     asm volatile("" : "+v"(si));                                       // keep the strength in a VGPR (SGPR operands issue at half rate)
     uint32_t i = 0;
@@ -332,7 +335,8 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
 #pragma unroll
         for (int j = 0; j < FT_UNROLL; ++j) {
             const float dx = prm[j].x - p.x, dy = prm[j].y - p.y, dz = prm[j].z - p.z;
-            q[j] = __builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN);
+            q[j] = (dx * dx + dy * dy) + dz * dz;
+            if (CLAMP) q[j] = __builtin_fmaxf(q[j], FT_FAST_Q_MIN);
         }
 #pragma unroll
         for (int j = 0; j < FT_UNROLL; ++j) sum = sum + ft_exp_fast<NEAR>(ft_strength_times_diff<PW>(si, FT_LOOP_SQRT(q[j]), prm[j].w));
@@ -340,7 +344,8 @@ __device__ __forceinline__ float smooth_run_spheres_fast(const float* __restrict
     for (; i < count; ++i) {
         const float4 prm = *reinterpret_cast<const float4*>(ldsC + 4 * i);
         const float dx = prm.x - p.x, dy = prm.y - p.y, dz = prm.z - p.z;
-        sum = sum + ft_exp_fast<NEAR>(ft_strength_times_diff<PW>(si, FT_LOOP_SQRT(__builtin_fmaxf((dx * dx + dy * dy) + dz * dz, FT_FAST_Q_MIN)), prm.w));
+        const float q1 = (dx * dx + dy * dy) + dz * dz;
+        sum = sum + ft_exp_fast<NEAR>(ft_strength_times_diff<PW>(si, FT_LOOP_SQRT(CLAMP ? __builtin_fmaxf(q1, FT_FAST_Q_MIN) : q1), prm.w));
     }
 #ifndef FT_SQRT_5
     if (NEAR) ft_omod_off(mode, sum);
@@ -514,6 +519,7 @@ __device__ __forceinline__ void eval_union_prims(const FtSceneDev& S, const FtGr
 }
 
 #define FT_CULL_NONE 0xffffffffu
+#define FT_CULL_NOCLAMP 0x10000u               // flag on ft_cull_children's survivor count (<= FT_CULL_MAX = 256): no ray of the wave is within 1e-6 of a child's centre this round
 // the interpreter (below); WITH_UNION = false is the instance the candidate loop uses for FT_PR_CALL children,
 // which contain no union by construction (scene.cpp emitUnion) — that keeps the two mutually non-recursive
 template <bool WITH_UNION, bool CALLS, int MATH, bool COOP = false>
@@ -681,7 +687,7 @@ __device__ __forceinline__ void ft_exec(const FtSceneDev& S, uint32_t pc, uint32
                 // from the wave's LDS row and then the rest of the run in full ("Exact child culling" below; the lean kernel does the same)
                 const bool culled = pc == S.cullPc && cullN != FT_CULL_NONE;
                 const float* c = culled ? cullRow : ldsC + in.data;
-                uint32_t n = culled ? cullN : in.count;
+                uint32_t n = culled ? (cullN & 0xffffu) : in.count;
                 uint32_t rest = culled && in.count > FT_CULL_MAX ? in.count - FT_CULL_MAX : 0u;
 #pragma nounroll
                 for (;;) {
@@ -870,12 +876,17 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
     float4* dst = reinterpret_cast<float4*>(row);
     float carry = 0.0f;                                                // sum of the lower bounds of the passes done (wave-uniform)
     uint32_t kept = 0;
+    bool apart = true;                                                 // every child looked at keeps its centre away from every ray's point (wave-uniform)
     for (uint32_t base = 0; base < n; base += 64u) {
         const uint32_t i = base + lane;
         const bool have = i < n;
         const float4 prm = src[have ? i : n - 1u];
         const float dx = prm.x - q0.x, dy = prm.y - q0.y, dz = prm.z - q0.z;
-        const float dc = __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) - prm.w;      // |c - q0| - r, within a few ulp of 20000
+        const float dq = __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz);             // |c - q0| (v_sqrt_f32: 1 ulp)
+        const float dc = dq - prm.w;                                   // |c - q0| - r, within a few ulp of 20000
+        // |c - p| >= |c - q0| - |p - q0| >= dq (1 - 3e-7) - rho for every ray's p (rho is an upper bound by construction): with the margin below every squared
+        // distance the sphere loop forms is >= 1e-12 (close differences are exact, its five roundings lose < 1e-6 of that) — far above the 2^-96 clamp
+        if (__ballot(have && !(dq - rho >= 1e-5f * dq + 1e-6f)) != 0ull) apart = false;
         const float slack = 0.01f + rho;                               // 0.01 >> every rounding here and in the lanes' own distances
         const float dlo = dc - slack, dhi = dc + slack;
         const float low = have ? __builtin_amdgcn_exp2f(__builtin_fmaxf(si * dhi * 1.44269504f - 0.02f, -200.0f)) : 0.0f;
@@ -893,7 +904,7 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
         kept += (uint32_t)__popcll(km);
         carry += passTotal;
     }
-    return kept;
+    return kept | (apart ? FT_CULL_NOCLAMP : 0u);
 }
 
 // Lean evaluator for scenes whose whole program is {fast sphere SMOOTH_RUN..., SMOOTH_FIN, SETLEAF}
@@ -902,7 +913,7 @@ __device__ __forceinline__ uint32_t ft_cull_children(const FtSceneDev& S, const 
 // one run of sphere children in the regime the evaluation allows (wave-uniform fastOk / nearOk): sum0 + the run's terms, in list order
 template <int MATH>
 __device__ __forceinline__ float ft_run_spheres(const FtSceneDev& S, const float* __restrict__ c, uint32_t count, float si, const f3 p, float sum0,
-                                                bool fastOk, bool nearOk) {
+                                                bool fastOk, bool nearOk, bool noClamp = false) {
     if (MATH != 0) {                                                   // FT_OPT_MATH: glibc's expf
         const ft_u64* tab = ft_libm_tab(S);
         if (S.mathFma) return nearOk ? smooth_run_spheres_libm<true, true, true>(c, count, si, p, sum0, tab)
@@ -915,6 +926,12 @@ __device__ __forceinline__ float ft_run_spheres(const FtSceneDev& S, const float
     if (__builtin_expect(nearOk, 1)) {
 #ifndef FT_SQRT_5
         const int pw = ft_strength_pw(si);                             // wave-uniform: the strength is an instruction field
+        if (noClamp) {                                                 // survivors of a culling pass that found every centre away from every ray's point
+            if (pw == 2) return smooth_run_spheres_fast<true, 2, false>(c, count, si, p, sum0);
+            if (pw == 1) return smooth_run_spheres_fast<true, 1, false>(c, count, si, p, sum0);
+            if (pw == 3) return smooth_run_spheres_fast<true, 3, false>(c, count, si, p, sum0);
+            return smooth_run_spheres_fast<true, 0, false>(c, count, si, p, sum0);
+        }
         if (pw == 2) return smooth_run_spheres_fast<true, 2>(c, count, si, p, sum0);
         if (pw == 1) return smooth_run_spheres_fast<true, 1>(c, count, si, p, sum0);
         if (pw == 3) return smooth_run_spheres_fast<true, 3>(c, count, si, p, sum0);
@@ -943,13 +960,14 @@ __device__ __forceinline__ void ft_eval_smooth_spheres(const FtSceneDev& S, cons
             // LDS row) and then the rest of the run in full; one inlined copy of the loops serves both pieces
             const bool culled = pc == S.cullPc && cullN != FT_CULL_NONE && fastOk;
             const float* c = culled ? cullRow : ldsC + in->data;
-            uint32_t n = culled ? cullN : in->count;
+            uint32_t n = culled ? (cullN & 0xffffu) : in->count;
             uint32_t rest = culled && in->count > FT_CULL_MAX ? in->count - FT_CULL_MAX : 0u;
+            bool noClamp = culled && (cullN & FT_CULL_NOCLAMP) != 0u;     // holds for the children the pass looked at: the survivors in the row
 #pragma nounroll
             for (;;) {
-                acc = ft_run_spheres<MATH>(S, c, n, in->f0, p, acc, fastOk, nearOk);
+                acc = ft_run_spheres<MATH>(S, c, n, in->f0, p, acc, fastOk, nearOk, noClamp);
                 if (rest == 0u) break;
-                c = ldsC + in->data + 4u * FT_CULL_MAX; n = rest; rest = 0u;
+                c = ldsC + in->data + 4u * FT_CULL_MAX; n = rest; rest = 0u; noClamp = false;
             }
         }
         else if (op == FT_OP_SMOOTH_FIN) acc = -ft_log_m<MATH>(acc, S) * in->f0;
@@ -1572,7 +1590,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             if (cullN != FT_CULL_NONE) {
                 const uint32_t cnt = (as_const(a.S.instr) + a.S.cullPc)->count;
                 const uint32_t looked = cnt < FT_CULL_MAX ? cnt : FT_CULL_MAX;
-                cullTotal += looked * (uint32_t)__popcll(am) >> 6; cullSkipped += (looked - cullN) * (uint32_t)__popcll(am) >> 6;   // in units of 64 pairs
+                cullTotal += looked * (uint32_t)__popcll(am) >> 6; cullSkipped += (looked - (cullN & 0xffffu)) * (uint32_t)__popcll(am) >> 6;   // in units of 64 pairs
             }
         }
         if (active) {
