@@ -156,3 +156,41 @@ def test_header_is_plain_c99_with_the_reference_layouts(tmp_path):
     for cname, ctype in (("ft_ray", _lib.Ray), ("ft_camera", _lib.CameraS), ("ft_render_params", _lib.RenderParams), ("ft_stats", _lib.Stats),
                          ("ft_triangle", _lib.Triangle), ("ft_torus", _lib.Torus), ("ft_capsule", _lib.Capsule)):
         assert C.sizeof(ctype) == got[("sizeof", cname)], cname
+
+
+def test_the_makefile_lists_every_header_an_object_includes():
+    """capi.o embeds the hash of ALL sources (ft_build_info), so an object that misses a header in its rule could stay stale while the
+    hash moves on — the stale-build failure the hash exists to prevent.  Every `name.o:` rule of csrc/Makefile must list every project header its
+    source includes, directly or through another header."""
+    csrc = os.path.join(ROOT, "fraytracer_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read().replace("$(ABI)", "../../include/fraytracer_hip.h")
+
+    def includes(path, seen):
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(path).read(), flags=re.M):
+            full = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+            if full not in seen and os.path.exists(full):
+                seen.add(full)
+                includes(full, seen)
+        return seen
+
+    for obj, src in (("kernels.o", "kernels.hip"), ("scene.o", "scene.cpp"), ("capi.o", "capi.cpp"), ("multi.o", "multi.cpp")):
+        rule = re.search(r"^%s:(.*)$" % re.escape(obj), mk, flags=re.M).group(1).split()
+        listed = {os.path.normpath(os.path.join(csrc, r)) for r in rule}
+        need = includes(os.path.join(csrc, src), set())
+        need.discard(os.path.join(csrc, "build_hash.h")) if obj != "capi.o" else None
+        missing = sorted(os.path.relpath(n, csrc) for n in need if n not in listed)
+        assert not missing, f"{obj}: the Makefile rule does not list {missing}"
+
+
+def test_glibc_build_of_this_host_asks_the_running_libm():
+    """the build of glibc's expf the ifunc resolver picked is decided by evaluating the two inputs on which the FMA and SSE2 builds differ,
+    not by parsing /proc/cpuinfo: a child process whose libm is switched by GLIBC_TUNABLES must report the other build."""
+    import sys
+    here = ft.glibc_build_of_this_host()
+    assert here in (_lib.FT_MATH_GLIBC_FMA, _lib.FT_MATH_GLIBC_SSE2)
+    code = "import sys; sys.path.insert(0, %r); import fraytracer_amd as ft; print(ft.glibc_build_of_this_host())" % ROOT
+    env = dict(os.environ, GLIBC_TUNABLES="glibc.cpu.hwcaps=-FMA,-AVX2")
+    child = int(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip().splitlines()[-1])
+    assert child == _lib.FT_MATH_GLIBC_SSE2
+    if here == _lib.FT_MATH_GLIBC_FMA:
+        assert child != here

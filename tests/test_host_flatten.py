@@ -187,7 +187,11 @@ def _weird_scenes():
            mk(SdfForm.unionSmooth(0.7, [SdfForm.unionSmooth(0.2, [P.sphere(rng.pointInBall(3.0), 0.3) for _ in range(6)]),
                                         P.torus((1, 2, 0), (0, 0, 1), 1.5, 0.2), P.triangle((0, 0, 0), (5, 0.01, 0), (-4, 0.02, 0.1), 0.05),
                                         P.box((-3, 0, 1), (0.5, 2.0, 0.1))])),
-           mk(SdfForm.union([P.triangle((0, 0, 0), (1, 0, 0), (0.5, 1e-3, 0), 0.01), P.sphere((10, 10, 10), 0.1), P.capsule((0, -5, 0), (0, -5.001, 0), 0.2)]))]
+           mk(SdfForm.union([P.triangle((0, 0, 0), (1, 0, 0), (0.5, 1e-3, 0), 0.01), P.sphere((10, 10, 10), 0.1), P.capsule((0, -5, 0), (0, -5.001, 0), 0.2)])),
+           # round 4: the sphere children of an intersect lend their own spheres — a small one far from child 0's centre, a second even smaller one later in the list
+           mk(SdfForm.intersect([P.torus((0, 0, 0), (0, 1, 0), 6.0, 2.0), P.sphere((5.5, 0.5, 0), 1.5), P.capsule((5, 0, 0), (6, 1, 0), 3.0), P.sphere((6.0, 0, 0.2), 0.9)])),
+           mk(SdfForm.subtract(SdfForm.intersect([SdfForm.union([P.torus(rng.pointInBall(3.0), rng.pointOnSphere(1.0), 0.5, 0.2) for _ in range(12)]), P.sphere((0.5, 0, 0), 2.0)]),
+                               P.sphere((0, 1, -1), 1.2)))]
     return out
 
 
@@ -212,6 +216,30 @@ def test_support_sphere_holds_every_small_distance(host, oracle, make):
     outside = np.linalg.norm(pts.astype(np.float64) - np.array([cx, cy, cz]), axis=1) - R
     ok = np.isnan(d) | (d >= outside)                                  # NaN never compares below epsilon
     assert ok.all(), (pts[~ok][:5], d[~ok][:5], outside[~ok][:5])
+
+
+def test_support_sphere_of_an_intersect_and_its_paddings(host):
+    """Round 4: an intersect's support sphere is the smallest of child 0's and its sphere children's own spheres (Program.fs: the 3.5 sphere, not
+    the tori's 4.7); the radius carries the evaluation padding and the drift padding of scene.cpp; a non-finite primitive constant ANYWHERE in
+    the tree (also where the support rules never look) means no sphere at all."""
+    P = SdfForm.Primitive
+    mat = SdfMaterial.createSolid((0.5, 0.5, 0.5))
+    cx, cy, cz, R = host.scene(syn.console_scene(n=200)[0]).support_sphere()
+    assert (cx, cy, cz) == (0.0, 0.0, 0.0) and 3.5 + 0.0135 < R < 3.6          # r + padEval < escR (padDrift on top), far below the tori's sphere
+    rng = syn.Rng(4)
+    blobs = SdfObject.union([SdfObject.create(mat, P.sphere(rng.pointInBall(3.0), 0.5)) for _ in range(20)])
+    two = SdfScene(SdfObject.intersect(blobs, [P.sphere((0.0, 0.0, 0.0), 9.0), P.sphere((0.5, 0.0, 0.0), 2.0)]), syn.BACKGROUND, [])
+    cx, cy, cz, R = host.scene(two).support_sphere()
+    assert (cx, cy, cz) == (0.5, 0.0, 0.0) and 2.0 < R < 2.1                     # the smallest sphere child wins, whatever its position in the list
+    capsule_child = SdfScene(SdfObject.intersect(blobs, [P.capsule((0.0, 0.0, 0.0), (0.1, 0.0, 0.0), 0.3)]), syn.BACKGROUND, [])
+    assert host.scene(capsule_child).support_sphere()[3] > 3.0                   # only sphere children are used (their pruning bound is the sphere itself)
+    ball = SdfObject.create(mat, P.sphere((0.0, 0.0, 0.0), 0.5))
+    for bad in (P.capsule((1.0, 0.0, 0.0), (1.0, 0.0, 0.0), 0.2), P.triangle((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (2.0, 2.0, 2.0), 0.1)):
+        for obj in (SdfObject.subtract(ball, bad), SdfObject.intersect(ball, [P.sphere((0.1, 0.0, 0.0), 0.6), bad])):
+            assert host.scene(SdfScene(obj, syn.BACKGROUND, [])).support_sphere()[3] < 0
+    # far from the origin the paddings grow with the coordinates, the sphere stays usable
+    far = SdfScene(SdfObject.create(mat, P.sphere((5000.0, -3000.0, 4000.0), 2.0)), syn.BACKGROUND, [])
+    assert 2.0 + 12.0 < host.scene(far).support_sphere()[3] < 2.0 + 20.0
 
 
 def test_support_sphere_is_refused_where_it_cannot_be_proved(host):
