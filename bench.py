@@ -205,11 +205,11 @@ def main():
     # the reference does (its counters are the oracle's); the roofline prices that work, the timed launches run the product's defaults
     ref = None
     if not args.no_reference_launch:
-        dev.set_option("escape", 0)
+        dev.set_option("escape", 0); dev.set_option("reuse", 0)
         ds.render_device(syn.EPSILON, syn.RAY_LENGTH, size, cam, slab.data_ptr(), **tiling)
         torch.cuda.synchronize()
         ref = ds.collect_stats()
-        dev.set_option("escape", 1)
+        dev.set_option("escape", 1); dev.set_option("reuse", 1)
 
     if pipe is not None:                          # both render lanes settle (lean-kernel placement is timed per context) before anything counts
         for d_ in lanes:
@@ -325,12 +325,12 @@ def main():
         CW = 4000
         csize = ft.ImageSize(CW, CW)
         cbuf = torch.empty((CW, CW, 3), dtype=torch.float32, device="cuda")
-        dev.set_option("escape", 0); dev.set_option("lazy_union", 0)   # the reference's evaluation count: every ray marched to its end, every union walk run to its end (second launch: warm)
+        dev.set_option("escape", 0); dev.set_option("lazy_union", 0); dev.set_option("reuse", 0)   # the reference's evaluation count: every ray marched to its end, every union walk run to its end (second launch: warm)
         cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
         torch.cuda.synchronize(); cds.collect_stats()
         cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
         torch.cuda.synchronize(); cref = cds.collect_stats()
-        dev.set_option("escape", 1); dev.set_option("lazy_union", 1)
+        dev.set_option("escape", 1); dev.set_option("lazy_union", 1); dev.set_option("reuse", 1)
         cds.render_device(syn.EPSILON, syn.RAY_LENGTH, csize, cam, cbuf.data_ptr())
         torch.cuda.synchronize(); cds.collect_stats()
         for _ in range(args.steps):

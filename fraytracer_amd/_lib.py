@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FRAYTRACER_HIP_LIB: diagnostic builds only (tools/union_divergence.py); the product is the in-tree library
 LIB_PATH = os.environ.get("FRAYTRACER_HIP_LIB") or os.path.join(_HERE, "libfraytracer_hip.so")
 
-FT_OPT_REFILL_MIN, FT_OPT_MAX_BLOCKS_PER_CU, FT_OPT_HOST_CHUNKS, FT_OPT_HOST_PIN, FT_OPT_TAIL_K, FT_OPT_MATH, FT_OPT_GUIDED, FT_OPT_CHUNK, FT_OPT_CULL, FT_OPT_ESCAPE, FT_OPT_LAZY_UNION, FT_OPT_CARVED = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+FT_OPT_REFILL_MIN, FT_OPT_MAX_BLOCKS_PER_CU, FT_OPT_HOST_CHUNKS, FT_OPT_HOST_PIN, FT_OPT_TAIL_K, FT_OPT_MATH, FT_OPT_GUIDED, FT_OPT_CHUNK, FT_OPT_CULL, FT_OPT_ESCAPE, FT_OPT_LAZY_UNION, FT_OPT_CARVED, FT_OPT_REUSE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 FT_MATH_FIXED, FT_MATH_GLIBC_FMA, FT_MATH_GLIBC_SSE2 = 0, 1, 2
 FT_OK, FT_ERR_INVALID, FT_ERR_NO_DEVICE, FT_ERR_HIP, FT_ERR_UNSUPPORTED, FT_ERR_EMPTY, FT_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 

@@ -377,7 +377,7 @@ class Device:
 
     OPTIONS = {"refill_min": _lib.FT_OPT_REFILL_MIN, "max_blocks_per_cu": _lib.FT_OPT_MAX_BLOCKS_PER_CU,
                "host_chunks": _lib.FT_OPT_HOST_CHUNKS, "host_pin": _lib.FT_OPT_HOST_PIN, "math": _lib.FT_OPT_MATH,
-               "tail_k": _lib.FT_OPT_TAIL_K, "guided": _lib.FT_OPT_GUIDED, "chunk": _lib.FT_OPT_CHUNK, "cull": _lib.FT_OPT_CULL, "escape": _lib.FT_OPT_ESCAPE, "lazy_union": _lib.FT_OPT_LAZY_UNION, "carved": _lib.FT_OPT_CARVED}
+               "tail_k": _lib.FT_OPT_TAIL_K, "guided": _lib.FT_OPT_GUIDED, "chunk": _lib.FT_OPT_CHUNK, "cull": _lib.FT_OPT_CULL, "escape": _lib.FT_OPT_ESCAPE, "lazy_union": _lib.FT_OPT_LAZY_UNION, "carved": _lib.FT_OPT_CARVED, "reuse": _lib.FT_OPT_REUSE}
 
     def set_option(self, name, value):
         """ft_ctx_set_option: per-context switches (the library reads no environment variables)"""

@@ -62,6 +62,7 @@ struct ft_ctx {
     int optEscape = 1;                                     // FT_OPT_ESCAPE: rays that can no longer reach the scene's support sphere end as misses at once (kernels.hip ft_never_enters)
     int optLazyUnion = 1;                                  // FT_OPT_LAZY_UNION: a union under an intersect stops at Items.[0] where the intersect's next child decides (kernels.hip)
     int optCull = 1;                                       // FT_OPT_CULL: exact child culling in the lean kernel (kernels.hip); 0 = every child, every round
+    int optReuse = 1;                                      // FT_OPT_REUSE: a secondary ray's first evaluation is taken from the normal's centre probe (kernels.hip FT_SH_D0); 0 = evaluated again, as the reference does
     int optCarved = 1;                                     // FT_OPT_CARVED: scenes of the "carved union" shape take their specialised kernel (kernels.hip ft_eval_carved); 0 = the general interpreter
     int optGuided = 0;                                     // FT_OPT_GUIDED: smaller chunks at the end of the job queue (lean kernel; measured: no gain)
 };
@@ -319,6 +320,7 @@ int launchTrace(ft_ctx* c, const ft_scene* s, FtRenderArgs& a, int lane = 0) {
     a.cull = (s->dev.cullPc != 0xffffffffu && variant != 3u && cullRows && c->optCull) ? 1u : 0u;
     if (!c->optEscape) a.S.escR = -1.0f;
     a.lazy = c->optLazyUnion ? 1u : 0u;
+    a.reuse = c->optReuse ? 1u : 0u;
     a.S.mathFma = c->optMath == FT_MATH_GLIBC_FMA ? 1u : 0u;
     a.materialsExt = s->dMaterialsExt;
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
@@ -374,6 +376,7 @@ int ft_ctx_set_option(ft_ctx* c, int32_t option, int32_t value) {
     case FT_OPT_CULL: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CULL: 0 or 1"); c->optCull = value; return FT_OK;
     case FT_OPT_GUIDED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_GUIDED: 0 or 1"); c->optGuided = value; return FT_OK;
     case FT_OPT_CARVED: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_CARVED: 0 or 1"); c->optCarved = value; return FT_OK;
+    case FT_OPT_REUSE: if (value != 0 && value != 1) return setErr(FT_ERR_INVALID, "FT_OPT_REUSE: 0 or 1"); c->optReuse = value; return FT_OK;
     case FT_OPT_MATH:
         if (value != FT_MATH_FIXED && value != FT_MATH_GLIBC_FMA && value != FT_MATH_GLIBC_SSE2) return setErr(FT_ERR_INVALID, "FT_OPT_MATH: 0 fixed, 1 glibc (FMA build), 2 glibc (SSE2 build)");
         c->optMath = value; return FT_OK;
@@ -391,6 +394,7 @@ int ft_ctx_get_option(const ft_ctx* c, int32_t option, int32_t* value) {
     case FT_OPT_TAIL_K: *value = c->optTailK; return FT_OK;
     case FT_OPT_GUIDED: *value = c->optGuided; return FT_OK;
     case FT_OPT_CARVED: *value = c->optCarved; return FT_OK;
+    case FT_OPT_REUSE: *value = c->optReuse; return FT_OK;
     case FT_OPT_CULL: *value = c->optCull; return FT_OK;
     case FT_OPT_LAZY_UNION: *value = c->optLazyUnion; return FT_OK;
     case FT_OPT_ESCAPE: *value = c->optEscape; return FT_OK;

@@ -15,7 +15,7 @@
 #else
 #define FT_LDS_DBG_ROWS 0
 #endif
-#define FT_SH_ROWS 9          // hit position, normal, accumulated light (3 each)
+#define FT_SH_ROWS 10         // hit position, normal, accumulated light (3 each), the distance at the hit position
 #define FT_LDS_SH_BASE (FT_LDS_CNT_WORDS + FT_LDS_DBG_ROWS * FT_BLOCK)
 #define FT_LDS_HDR_FLOATS (FT_LDS_SH_BASE + FT_SH_ROWS * FT_BLOCK)
 // lean kernel: every wave owns a row of FT_CULL_MAX float4 records behind everything else (kernels.hip "Exact child culling").  With 256 staged
@@ -51,6 +51,7 @@ struct FtRenderArgs {
     const float* materialsExt;   // EXTENSION: 4 floats per material (glass flag, ior, dispersion, 0); kept out of
                                  // FtSceneDev so that the reference kernels' argument layout does not move
     float spec[16][4];        // per bin: RGB weight, Cauchy term (ft_spectral_table)
+    uint32_t reuse;           // 1: a secondary ray's first evaluation — at the hit position — is the value the normal's centre probe computed there (FT_OPT_REUSE; kernels.hip FT_SH_D0)
     FtCarve carve;            // FtSceneDev.fastPath == 3: the union's tail and its terminated candidate lists (ft_device.h "Carved union")
 };
 

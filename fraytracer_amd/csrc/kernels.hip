@@ -92,8 +92,12 @@ __device__ __forceinline__ void ft_flag(uint32_t bits) {              // `bits` 
 // The intensity and cosine of the light a shadow ray belongs to are not kept (round 3 did: four more rows, 4 KB per workgroup — the lean kernel's fifth
 // workgroup per CU): when the ray has missed they are formed again from the light's record, the hit position and the normal, by the operations that
 // formed them when the ray was started — same operands, same roundings, same bits.
-enum : uint32_t { FT_SH_HP = 0, FT_SH_NRM = 3, FT_SH_LACC = 6 };
-static_assert(FT_SH_LACC + 3 <= FT_SH_ROWS, "ft_kernels.h: FT_SH_ROWS");
+// FT_SH_D0 (round 4): the scene's distance at the hit position — the value the fourth normal probe has just computed there (SdfForm.fs:112: D(p) at
+// p = Ray.get(-eps), which is SdfObject.fs:73's pulled-back origin, the same expression on the same operands).  Every shadow ray (SdfLight.fs:11-16, 31-36)
+// and every EXTENSION ambient-occlusion ray starts at exactly that point, so the first evaluation of its march is this number again: it is taken from here
+// instead of being computed a second, third ... time (FT_OPT_REUSE; the reference evaluates it once per light).
+enum : uint32_t { FT_SH_HP = 0, FT_SH_NRM = 3, FT_SH_LACC = 6, FT_SH_D0 = 9 };
+static_assert(FT_SH_D0 + 1 <= FT_SH_ROWS, "ft_kernels.h: FT_SH_ROWS");
 __device__ __forceinline__ float* ft_sh(uint32_t row) { return ft_lds + FT_LDS_SH_BASE + row * FT_BLOCK + threadIdx.x; }
 __device__ __forceinline__ f3 sh_get3(uint32_t row) { const float* q = ft_sh(row); return mk3(q[0], q[FT_BLOCK], q[2 * FT_BLOCK]); }
 __device__ __forceinline__ void sh_set3(uint32_t row, f3 v) { float* q = ft_sh(row); q[0] = v.x; q[FT_BLOCK] = v.y; q[2 * FT_BLOCK] = v.z; }
@@ -1297,6 +1301,19 @@ __device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o,
     return cc * dd - b * b > tol * dd;
 }
 
+// The first step of a ray that starts at the hit position, from the distance already known there (FT_SH_D0): exactly what the round's switch does with an
+// evaluated distance for a PH_SHADOW / PH_AO lane (SdfForm.fs:94-104).  -> 0 the ray marches on (s.o, s.len, s.steps advanced), 1 it is a hit at once, 2 it
+// ends as a miss (NaN distance, flagged like there).
+__device__ __forceinline__ int first_step_from_cache(LaneState& s) {
+    const float d = *ft_sh(FT_SH_D0);
+    if (d != d) { ft_flag(1u); return 2; }                             // reference would never terminate
+    if (d < s.eps) return 1;                                           // SdfForm.fs:98
+    s.o = s.o + s.dir * d;                                             // Ray.move (Ray.fs:9-13)
+    s.len = s.len - d;
+    s.steps = 1;
+    return 0;
+}
+
 // advance a lane until it needs an SDF evaluation (or is idle): everything in SdfScene.trace that
 // is not a Distance call.
 template <bool EXT>
@@ -1329,6 +1346,11 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
             if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) { s.xs += 0x101u; continue; }
             s.o = sh_get3(FT_SH_HP); s.dir = dir; s.len = a.aoRadius; s.steps = 0;
             s.phase = PH_AO;
+            if (a.reuse != 0u) {
+                const int r = first_step_from_cache(s);
+                if (r == 1) { s.xs += 1u; s.phase = PH_AONEXT; }      // occluded at once
+                else if (r == 2) s.len = -1.0f;                        // resolved as unoccluded by the PH_AO branch above, like a miss of the round's switch
+            }
             continue;
         }
         if (s.phase == PH_SHADOW) {
@@ -1371,6 +1393,11 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
                 }
                 s.steps = 0; ft_count(FT_C_SHADOW);
                 s.phase = PH_SHADOW;
+                if (a.reuse != 0u) {
+                    const int r = first_step_from_cache(s);
+                    if (r == 1) { ft_count(FT_C_HITS); s.lidx += 1; s.phase = PH_LIGHTS; }     // shadowed at once (SdfLight.fs:20)
+                    else if (r == 2) s.len = -1.0f;                    // resolved as a miss by the PH_SHADOW branch above
+                }
                 continue;
             }
             s.lidx += 1;
@@ -1638,6 +1665,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             case PH_NY: *ft_sh(FT_SH_NRM + 1) = d; s.phase = PH_NZ; break;
             case PH_NZ: *ft_sh(FT_SH_NRM + 2) = d; s.phase = PH_NC; break;
             case PH_NC: {
+                *ft_sh(FT_SH_D0) = d;                                  // D at the hit position: the first evaluation of every ray that starts there
                 const f3 nrm = ft_normalize(sh_get3(FT_SH_NRM) - splat3(d));   // SdfForm.fs:107-112
                 const f3 hp = s.o + s.dir * (-s.eps);                  // SdfObject.fs:73
                 sh_set3(FT_SH_NRM, nrm);
