@@ -1214,7 +1214,9 @@ __device__ __forceinline__ void ft_eval_carved(const FtSceneDev& S, const FtCarv
 // render / trace kernel
 // ------------------------------------------------------------------------------------------------
 // phases >= PH_MARCH need one scene-SDF evaluation per round
-enum : uint32_t { PH_IDLE = 0, PH_DONE, PH_LIGHTS, PH_AONEXT, PH_MARCH, PH_NX, PH_NY, PH_NZ, PH_NC, PH_SHADOW, PH_AO };
+// PH_CAM (round 4, FT_OPT_REUSE): the wave's very first round in Image.render mode — every lane evaluates the scene at the camera position, where every primary ray
+// of the frame starts (Camera.fs:52: Origin = Position), so that each ray's first march step can be taken from that one value instead of evaluating it per ray
+enum : uint32_t { PH_IDLE = 0, PH_DONE, PH_LIGHTS, PH_AONEXT, PH_MARCH, PH_NX, PH_NY, PH_NZ, PH_NC, PH_SHADOW, PH_AO, PH_CAM };
 
 // EXTENSION: fixed ambient-occlusion directions (16 Fibonacci-sphere points); the ray k leaves the hit
 // point along normalize(Normal + FT_AO_DIRS[k]).  Same table as the oracle's AO_DIRS.
@@ -1408,7 +1410,7 @@ __device__ __forceinline__ void settle(const FtRenderArgs& a, LaneState& s) {
 }
 
 template <bool EXT>
-__device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
+__device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s, const bool camKnown, const float dCam, const uint32_t leafCam) {
     if (a.mode >= 1) {                                                 // explicit ray buffer (SdfScene.trace scene ray; 2, 3: tryTrace entries)
         const ft_ray r = a.rays[s.job];
         s.o = mk3(r.origin.x, r.origin.y, r.origin.z);
@@ -1441,6 +1443,11 @@ __device__ __forceinline__ void start_job(const FtRenderArgs& a, LaneState& s) {
     if (EXT) s.xs &= 0xffffu;                                          // outside, no interaction yet
     s.steps = 0; ft_count(FT_C_PRIMARY);
     s.phase = PH_MARCH;
+    if (camKnown && s.len > 0.0f) {                                    // the ray's first evaluation is Distance(camera position) (SdfForm.fs:94-96): known, see PH_CAM — what the round's
+        if (dCam != dCam) { ft_flag(1u); s.len = -1.0f; }              // switch does with it for a PH_MARCH lane: NaN (flagged, a miss),
+        else if (dCam < s.eps) { ft_count(FT_C_HITP); s.leaf = leafCam; s.phase = PH_NX; }   // a hit at the camera itself,
+        else { s.o = s.o + s.dir * dCam; s.len = s.len - dCam; s.steps = 1; }               // or the first step (Ray.fs:9-13)
+    }
     settle<EXT>(a, s);
 }
 
@@ -1530,6 +1537,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
     s.len = 0; s.eps = 0;
     s.xs = 0;
     s.thr = splat3(1.0f); s.seed = 0;
+    // FT_OPT_REUSE: the first round of a wave in Image.render mode evaluates the scene at the camera position in every lane (PH_CAM)
+    bool camKnown = false;
+    float dCam = 0.0f; uint32_t leafCam = 0u;                          // wave-uniform
+    if (a.reuse != 0u && a.mode == 0u) { s.phase = PH_CAM; s.o = mk3(a.cam[0], a.cam[1], a.cam[2]); s.eps = a.eps; }
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk ------------------------------------------
@@ -1564,7 +1575,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
             const uint32_t avail = chunkEnd - chunkNext;
             const uint32_t nIdle = (uint32_t)__popcll(idle);
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (s.phase == PH_IDLE && rank < avail) { s.job = chunkNext + rank; start_job<EXT>(a, s); }
+            if (s.phase == PH_IDLE && rank < avail) { s.job = chunkNext + rank; start_job<EXT>(a, s, camKnown, dCam, leafCam); }
             chunkNext += (nIdle < avail) ? nIdle : avail;
         }
         if (s.phase == PH_IDLE && exhausted && chunkNext == chunkEnd) s.phase = PH_DONE;
@@ -1588,7 +1599,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         };
         // ---- latency mode: at most tailK rays left in this wave -> each is evaluated by all 64 lanes together ("Latency (tail) mode") ----
         const unsigned long long am = __ballot(active);
-        nEvals += (uint32_t)__popcll(am);
+        if (s.phase != PH_CAM) nEvals += (uint32_t)__popcll(am);       // (wave-uniform: all lanes are in PH_CAM together; that one evaluation per wave is not counted)
         const bool coop = (uint32_t)__popcll(am) <= a.tailK;           // tailK = 0: never
         float dCoop = 0.0f; uint32_t leafCoop = 0;
         if (coop && am != 0ull) {
@@ -1661,6 +1672,10 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                 if (miss) s.len = -1.0f;                               // resolved as a miss by settle()
                 break;
             }
+            case PH_CAM:                                               // all 64 lanes, the same point: the value every primary ray's first step is taken from
+                dCam = ft_readlane_f(d, 0); leafCam = (uint32_t)__builtin_amdgcn_readlane((int)leaf, 0); camKnown = true;
+                s.phase = PH_IDLE;
+                break;
             case PH_NX: *ft_sh(FT_SH_NRM) = d; s.phase = PH_NY; break;
             case PH_NY: *ft_sh(FT_SH_NRM + 1) = d; s.phase = PH_NZ; break;
             case PH_NZ: *ft_sh(FT_SH_NRM + 2) = d; s.phase = PH_NC; break;

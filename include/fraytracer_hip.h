@@ -131,7 +131,8 @@ typedef enum ft_option {
                                    * 0: the general interpreter kernel */
     FT_OPT_REUSE = 13,            /* 1 (default): every shadow ray (and EXTENSION ambient-occlusion ray) starts at the hit position, where the fourth probe of SdfForm.normal
                                    * has just evaluated the scene (SdfForm.fs:112, SdfObject.fs:73: the same point, bit for bit); the first evaluation of its march is
-                                   * that value and is not computed again (same frame, same ray and hit counters, fewer sdf_evals); 0: evaluated once per ray, as the reference does */
+                                   * that value and is not computed again; likewise every primary ray of ft_render starts at the camera position, which each wave evaluates
+                                   * once (same frame, same ray and hit counters, fewer sdf_evals); 0: evaluated once per ray, as the reference does */
     FT_OPT_GUIDED = 7             /* 1: the last jobs of a launch are handed out in half and quarter tiles (lean kernel); 0 (default): whole tiles only */
 } ft_option;
 /* MathF.Exp / MathF.Log (SdfForm.unionSmooth, SdfForm.fs:80,82) and MathF.Pow (FColor.gammaInverse, FColor.fs:50-55) are the C runtime's

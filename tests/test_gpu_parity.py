@@ -1548,9 +1548,10 @@ def test_a_scene_of_nan_constants_takes_no_escape_shortcut(gpu, oracle):
 
 def test_reusing_the_centre_probe_as_a_secondary_rays_first_step_changes_no_pixel(gpu, oracle):
     """FT_OPT_REUSE (round 4): every shadow ray and every EXTENSION ambient-occlusion ray starts at the pulled-back hit position, where the fourth
-    probe of SdfForm.normal has just evaluated the scene; its first evaluation is that value and is not computed again.  Frames, ray / hit counters,
-    flags and explicit rays are the oracle's with the option on and off, in every kernel family and with both light types; with it on
-    exactly one evaluation per secondary ray is saved."""
+    probe of SdfForm.normal has just evaluated the scene; its first evaluation is that value and is not computed again.  Likewise every primary ray of
+    Image.render starts at the camera position, which each wave evaluates once.  Frames, ray / hit counters, flags and explicit rays are the oracle's with
+    the option on and off, in every kernel family and with both light types; with it on exactly one evaluation per ray is saved (a camera inside an object —
+    a hit at step 0 — included)."""
     cam = syn.default_camera()
     cases = [("C3 lean", syn.config3(n=64, size=128)[0], {}), ("C2 carved mixed", syn.config2(seed=4, size=128)[0], {}),
              ("Program.fs structure, both lights", syn.console_scene(n=120, size=128)[0], {}), ("mixed nested (general)", syn.mixed_nested()[0], {}),
@@ -1589,12 +1590,26 @@ def test_reusing_the_centre_probe_as_a_secondary_rays_first_step_changes_no_pixe
                 for reuse in (1, 0):
                     gpu.set_option("reuse", reuse)
                     _, st = ds.render(EPS, LEN, ft.ImageSize(W, H), cam, **{k: v for k, v in kw.items() if k != "max_bounces" and k != "spectral"})
-                    n[reuse] = (st["sdf_evals"], st["rays_shadow"] + (st["rays_ext"] if "ao_samples" in kw else 0))
+                    n[reuse] = (st["sdf_evals"], st["rays_primary"] + st["rays_shadow"] + (st["rays_ext"] if "ao_samples" in kw else 0))
             finally:
                 gpu.set_option("escape", 1)
             if "max_bounces" not in kw:
                 assert n[0][0] - n[1][0] == n[1][1], (name, n)
             assert evals[1] <= evals[0]
+            ds.close()
+        # the camera inside an object (first evaluation is a hit: material and normal come from the shared value) and inside the carved-out sphere of the reference's structure
+        from fraytracer_amd import Camera, Lens
+        for name, scene, pos in (("camera inside a blob", syn.config3(n=40, size=64)[0], None), ("camera inside the Program.fs structure", syn.console_scene(n=150, size=64)[0], (-0.5, 1.0, -2.0))):
+            ds, os_ = both(gpu, oracle, scene)
+            if pos is None:
+                pos = tuple(np.asarray(scene.Object.kids[1].kids[0].args[0], np.float32).tolist())      # the centre of the first sphere
+            cam2 = Camera.lookAt(Position=pos, LookAt=(0.3, 0.2, 5.0), Up=(0.0, 1.0, 0.0), Lens=Lens.create(60.0))
+            want, ocnt = os_.render(EPS, LEN, 72, 56, cam2.as_array())
+            for reuse in (1, 0):
+                gpu.set_option("reuse", reuse)
+                g, gst = ds.render(EPS, LEN, ft.ImageSize(72, 56), cam2)
+                assert_bit_equal(g, want, f"{name}, reuse {reuse}")
+                check_counts(gst, ocnt)
             ds.close()
     finally:
         gpu.set_option("reuse", 1); gpu.set_option("escape", 1)
