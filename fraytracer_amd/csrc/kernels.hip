@@ -1599,14 +1599,15 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
         };
         // ---- latency mode: at most tailK rays left in this wave -> each is evaluated by all 64 lanes together ("Latency (tail) mode") ----
         const unsigned long long am = __ballot(active);
-        if (s.phase != PH_CAM) nEvals += (uint32_t)__popcll(am);       // (wave-uniform: all lanes are in PH_CAM together; that one evaluation per wave is not counted)
+        const bool camRound = __ballot(s.phase == PH_CAM) != 0ull;     // all lanes are in PH_CAM together; that one evaluation per wave is not counted in the statistics
+        if (!camRound) nEvals += (uint32_t)__popcll(am);
         const bool coop = (uint32_t)__popcll(am) <= a.tailK;           // tailK = 0: never
         float dCoop = 0.0f; uint32_t leafCoop = 0;
         if (coop && am != 0ull) {
             const f3 qm = query_point();
             if (VARIANT == 1) {                                        // smooth union of spheres: all the rays at once, 64 / rays lanes each
                 ft_eval_smooth_spheres_packed<MATH>(a.S, qm, active, am, (uint32_t)__popcll(am), ldsC, coopRow, dCoop, leafCoop);
-                coopEvals += (uint32_t)__popcll(am);
+                if (!camRound) coopEvals += (uint32_t)__popcll(am);
             } else {                                                   // general scenes: one ray after the other, all 64 lanes each
                 unsigned long long m = am;
                 while (m != 0ull) {
@@ -1617,7 +1618,7 @@ __device__ __forceinline__ void ft_trace_body(const FtRenderArgs& a) {
                     if (VARIANT == 3) ft_eval_carved<K, true>(a.S, a.carve, qL, dL, leafL, __builtin_inff());
                     else ft_eval_coop<VARIANT == 2, MATH>(a.S, qL, sd, sl, ldsC, dL, leafL);
                     if ((int)lane == L) { dCoop = dL; leafCoop = leafL; }
-                    coopEvals += 1;
+                    if (!camRound) coopEvals += 1;
                 }
             }
         }
