@@ -1283,14 +1283,14 @@ __device__ __forceinline__ void write_ray(float* o, f3 origin, f3 dir, float len
 // Only for rays whose remaining march stays where float32 cannot overflow (Length < 1e9, |dir| < 1e6, distance from the sphere < 1e15): there
 // every skipped evaluation is finite, so no NaN flag (SdfForm.fs: a NaN distance never terminates; flagged by the kernel and the oracle) is lost.
 // The line is not what the reference evaluates: it accumulates the origin in float32 step by step (Ray.fs:9-13).  escR carries a padding for that
-// drift, proved sufficient (scene.cpp "drift of the marched points") for epsilon >= 0 and either of two kinds of ray:
+// drift, proved sufficient (scene.cpp "drift of the marched points") for 0 <= epsilon <= escR and either of two kinds of ray:
 //   long rays   |dir| >= 1/2 and a start within sqrt(escRho2) of the centre (primary rays, directional shadow rays);
 //   short rays  of any |dir| whose whole remaining march stays within 2.5 escR of the centre and has Length <= 10 escR: every step is >= g, so there are at
 //               most Length / g + 1 <= 20 Rp / padDrift + 1 of them, each of error <= e(2.5 Rp) — the "near" budget of that bound.  (A point light's shadow
 //               ray has |dir| = 1 / distance and Length = distance, SdfLight.fs:28-30: it travels one unit.)  2 (|w|^2 + |dir|^2 Length^2) >= (|w| + |dir| Length)^2.
 // Any other ray simply marches on and is asked again at its next step.
 __device__ __forceinline__ bool ft_never_enters(const FtSceneDev& S, const f3 o, const f3 dir, float eps, float len) {
-    if (!(S.escR >= 0.0f) || !(len < 1e9f) || !(eps >= 0.0f)) return false;
+    if (!(S.escR >= 0.0f) || !(len < 1e9f) || !(eps >= 0.0f) || !(eps <= S.escR)) return false;
     const f3 w = o - mk3(S.escC[0], S.escC[1], S.escC[2]);
     const float re = S.escR + eps;
     const float ww = ft_dot(w, w), cc = ww - re * re, tol = 4e-6f * ww, dd = ft_dot(dir, dir);

@@ -855,17 +855,20 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
     //   padDrift — "drift of the marched points".  The reference moves the ray's origin step by step in float32 (Ray.fs:9-13: Origin + Direction * d), so the
     //     points it evaluates leave the line the shortcut reasons about (kernels.hip ft_never_enters).  One step that starts or ends at most rho from the centre c
     //     adds at most e(rho) = 3 * 2^-23 * (|c|inf + rho) to that drift (per component: the rounding of a product <= 2 rho and of a sum <= |c|inf + rho).
-    //     Let Rp = r + padEval + padDrift, a = |Direction| >= 1/2, epsilon >= 0, and suppose the drift so far is <= padDrift / 2.  Then every evaluated point
-    //     is >= r + padEval + epsilon + padDrift / 2 from c (the line stays >= escR + epsilon away), so each step is d >= g = epsilon + padDrift / 2 (support
-    //     property) and moves a d >= padDrift / 4 along the line.  Three kinds of steps:
-    //       near      (start and end within 2.5 Rp of c): the line's chord through that ball is <= 5 Rp long: at most 20 Rp / padDrift + 1 steps of error
-    //                 <= e(2.5 Rp) each.  padDrift is the root of  (20 Rp / padDrift + 1) e(2.5 Rp) = padDrift / 4.
-    //       approach  (start farther than 2.5 Rp, before the near steps): d >= rho - Rp >= rho / 2 moves >= rho / 4 along a line of which at most 2 rho are left
+    //     Let Rp = r + padEval + padDrift (= escR), a = |Direction| >= 1/2, 0 <= epsilon <= Rp, and suppose the drift so far is <= padDrift / 2.  The line stays
+    //     >= Rp + epsilon from c, so every evaluated point is >= r + padEval + epsilon + padDrift / 2 from c: no hit there, and each step is d >= g = epsilon + padDrift / 2
+    //     (support property), i.e. moves a d >= padDrift / 4 along the line.  Three kinds of steps:
+    //       near      (start and end within 5 Rp of c — that is >= 2.5 (Rp + epsilon)): the line's chord through that ball is <= 10 Rp long: at most 40 Rp / padDrift + 1
+    //                 steps of error <= e(5 Rp) each.  padDrift is the root of  (40 Rp / padDrift + 1) e(5 Rp) = padDrift / 4.
+    //       approach  (start farther than 5 Rp, before the near steps): d >= rho - Rp - epsilon >= rho / 2 moves >= rho / 4 along a line of which at most 2 rho are left
     //                 to the near ball, so that length shrinks by 7/8 per step: N(rho0) = 7.5 ln(8 rho0 / padDrift) + 1 steps from a start at rho0, each
     //                 <= e(rho0).  The kernel takes the shortcut only from starts with N(rho0) e(rho0) <= padDrift / 4 (escRho2, by bisection below).
-    //       receding  (rho >= 2.5 Rp, moving away): rho grows by >= sqrt(1 + a^2 / 4) >= 1.03 per step, so the errors form a geometric series
-    //                 < 34 * 3 * 2^-23 rho + e-terms in |c|inf that stay below rho / 100, against a margin rho - Rp - epsilon' that has grown to >= rho / 2.
+    //       receding  (rho >= 5 Rp, moving away): rho grows by >= sqrt(1 + a^2 / 4) >= 1.03 per step, so the errors of the steps so far form a geometric series
+    //                 <= 34 e-terms of the last one: < 1.3e-5 rho + 1.2e-5 |c|inf ln(rho / 5 Rp) <= rho / 50 (|c|inf <= 1000 Rp: padEval), against a margin
+    //                 rho - (r + padEval + epsilon) >= rho - 2 Rp >= 0.6 rho.
     //     Near and approach together stay <= padDrift / 2: the supposition holds step after step, every evaluated point keeps its distance, no step can be a hit.
+    //     (Short rays — kernels.hip: Length <= 10 escR, the whole march within 2.5 escR of c — make at most Length / g + 1 <= 20 Rp / padDrift + 1 steps of error
+    //     <= e(2.5 Rp): inside the near budget whatever |Direction| is.)
     Support sup;
     if (finiteTree(b, b.objects[object].form) && supportOf(b, b.objects[object].form, sup) && sup.r < 1e15 && std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]) < 1e15) {
         out.escC[0] = (float)sup.c[0]; out.escC[1] = (float)sup.c[1]; out.escC[2] = (float)sup.c[2];
@@ -873,10 +876,10 @@ bool flatten(const Builder& b, int object, const float bg[3], const int* lights,
         const double padEval = sup.r * 0.001 + 0.01 + 1e-3 * (std::fabs(sup.c[0]) + std::fabs(sup.c[1]) + std::fabs(sup.c[2]));
         const double u3 = 3.0 * 0x1p-23;
         double padDrift = 0.0;
-        for (int it = 0; it < 8; ++it) {                               // padDrift^2 - k padDrift - 20 k Rp = 0 with k = 4 e(2.5 Rp), Rp depending on padDrift
+        for (int it = 0; it < 8; ++it) {                               // padDrift^2 - k padDrift - 40 k Rp = 0 with k = 4 e(5 Rp), Rp depending on padDrift
             const double Rp = sup.r + padEval + padDrift;
-            const double k = 4.0 * u3 * (cInf + 2.5 * Rp);
-            padDrift = 1.01 * (0.5 * (k + std::sqrt(k * k + 80.0 * k * Rp)));
+            const double k = 4.0 * u3 * (cInf + 5.0 * Rp);
+            padDrift = 1.01 * (0.5 * (k + std::sqrt(k * k + 160.0 * k * Rp)));
         }
         out.escR = (float)((sup.r + padEval + padDrift) * (1.0 + 1e-6));
         auto approach = [&](double rho0) { return (7.5 * std::log(8.0 * rho0 / padDrift) + 1.0) * u3 * (cInf + rho0); };
