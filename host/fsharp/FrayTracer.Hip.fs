@@ -114,7 +114,9 @@ module Native =
     /// the running float32 sum, a ray that can no longer come within epsilon of the scene's support sphere ends as a miss at once, and a union under
     /// an intersect stops at Items.[0] where the intersect's next child already decides.  All are exact — the frame and the ray / hit counters do
     /// not change; `false` makes the GPU do every evaluation, child and candidate the CPU path does.  (FT_OPT_CARVED (12) only picks the kernel: the
-    /// specialised one for a union of primitives with at most two intersect / subtract steps behind it — Program.fs's own scene — or the interpreter.)
+    /// specialised one for a union of primitives with at most two intersect / subtract steps behind it — Program.fs's own scene — or the interpreter;
+    /// FT_OPT_REUSE (13, on) takes a ray's first evaluation from a value already known — a shadow ray's from the normal's centre probe, a primary ray's
+    /// from one evaluation at the camera position per wave — where the reference computes it again for every ray.)
     let setExactShortcuts (on : bool) =
         for opt in [ 9; 10; 11 ] do
             if ft_ctx_set_option (ctx.Value, opt, (if on then 1 else 0)) < 0 then failwith (Marshal.PtrToStringAnsi (ft_last_error ()))

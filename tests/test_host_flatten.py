@@ -242,6 +242,28 @@ def test_support_sphere_of_an_intersect_and_its_paddings(host):
     assert 2.0 + 12.0 < host.scene(far).support_sphere()[3] < 2.0 + 20.0
 
 
+def test_support_sphere_radius_follows_the_stated_padding_rule(host):
+    """escR = r + padEval + padDrift with padEval = 0.1 % r + 0.01 + 0.1 % |c|_1 and padDrift the root of
+    (40 Rp / padDrift + 1) * 3 * 2^-23 * (|c|inf + 5 Rp) = padDrift / 4, Rp = escR — recomputed here independently (fixed-point iteration in double) for spheres of
+    several sizes and positions: the flattener's radius must carry at least that much and at most 5 % more."""
+    P = SdfForm.Primitive
+    mat = SdfMaterial.createSolid((0.5, 0.5, 0.5))
+    u3 = 3.0 * 2.0 ** -23
+    for c, r in (((0.0, 0.0, 0.0), 1.0), ((0.0, 0.0, 0.0), 3.5), ((1.0, -2.0, 0.5), 0.05), ((300.0, 200.0, -100.0), 4.0), ((5000.0, -3000.0, 4000.0), 2.0), ((0.0, 0.0, 0.0), 900.0)):
+        R = host.scene(SdfScene(SdfObject.create(mat, P.sphere(c, r)), syn.BACKGROUND, [])).support_sphere()[3]
+        cinf, c1 = max(abs(v) for v in c), sum(abs(v) for v in c)
+        pad_eval = 0.001 * r + 0.01 + 0.001 * c1
+        pd = 0.0
+        for _ in range(60):
+            Rp = r + pad_eval + pd
+            k = 4.0 * u3 * (cinf + 5.0 * Rp)
+            pd = 0.5 * (k + (k * k + 160.0 * k * Rp) ** 0.5)
+        need = r + pad_eval + pd
+        assert need * (1 - 1e-6) <= R <= need * 1.05 + 1e-6, (c, r, R, need)
+        Rp = R
+        assert (40.0 * Rp / (R - r - pad_eval) + 1.0) * u3 * (cinf + 5.0 * Rp) <= (R - r - pad_eval) / 4.0 * (1 + 1e-9)      # the near-step budget really holds at the shipped radius
+
+
 def test_support_sphere_is_refused_where_it_cannot_be_proved(host):
     P = SdfForm.Primitive
     mat = SdfMaterial.createSolid((0.5, 0.5, 0.5))
