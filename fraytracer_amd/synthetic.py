@@ -252,13 +252,27 @@ def fuzz_scene_edge(seed):
     return _fuzz_scene(seed, False, True)
 
 
+FUZZ_INDEPENDENT_FROM = 10_000_000
+
+
+def _fuzz_stream(seed):
+    """Rng(s) and Rng(s + 1) are ONE splitmix stream read one draw apart, so scenes of neighbouring seeds are built from overlapping draws (an object
+    that makes the reference throw sits in every scene of a few thousand consecutive seeds).  Seeds from FUZZ_INDEPENDENT_FROM on are scrambled first:
+    unrelated streams.  Smaller seeds keep the scenes the committed fuzz records (profiles/) name."""
+    if seed < FUZZ_INDEPENDENT_FROM: return seed
+    z = (seed * 0xD6E8FEB86659FD93 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 32)) * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 32)) * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 32)
+
+
 def _fuzz_scene(seed, big, edge):
-    rng = Rng((0xB16 if big else 0xF00D) + seed)
+    rng = Rng((0xB16 if big else 0xF00D) + _fuzz_stream(seed))
     P0 = SdfForm.Primitive
     off = np.zeros(3, F)
     edge_eps, edge_len = None, RAY_LENGTH
     if edge:
-        er = Rng(0xED6E + seed)
+        er = Rng(0xED6E + _fuzz_stream(seed))
         off = np.array(((0.0, 0.0, 0.0), (5000.0, -3000.0, 4000.0), (300.0, 200.0, -100.0), (-40.0, 0.0, 25.0))[int(er.range_01() * 4) % 4], F)
         edge_eps = (1e-2, 1e-3, 1e-4, 1e-5)[int(er.range_01() * 4) % 4]
         edge_len = (30.0, 1000.0)[int(er.range_01() * 2) % 2]
