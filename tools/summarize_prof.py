@@ -50,7 +50,7 @@ for f, r in rows("trace/**/*kernel_trace.csv"):
         seen.add(name.split("(")[0].strip())
 for name in sorted(seen):
     print(f"code object: {name}: {resources.get(name, 'unknown')}")
-for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_ta", "pmc_tcp", "pmc_tcp2"):
+for name in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write", "pmc_ta", "pmc_ta2", "pmc_tcp", "pmc_tcp2"):
     acc = defaultdict(list)
     for f, r in rows(f"{name}/**/*counter_collection.csv"):
         if "ft_trace_kernel" in r.get("Kernel_Name", ""):
