@@ -271,3 +271,19 @@ def test_support_sphere_is_refused_where_it_cannot_be_proved(host):
     assert host.scene(weird).support_sphere()[3] < 0
     big = SdfScene(SdfObject.create(mat, P.sphere((0, 0, 0), 3e20)), syn.BACKGROUND, [])
     assert host.scene(big).support_sphere()[3] < 0
+
+
+def test_fuzz_scene_streams():
+    """synthetic._fuzz_stream: Rng(s) and Rng(s + 1) read ONE splitmix stream one draw apart, so below FUZZ_INDEPENDENT_FROM neighbouring fuzz seeds build
+    their scenes from overlapping draws (kept: the committed fuzz records name those seeds); from there on seeds are scrambled into unrelated streams."""
+    a, b = syn.Rng(1000), syn.Rng(1001)
+    a._next()
+    assert [a._next() for _ in range(4)] == [b._next() for _ in range(4)]                  # the overlap the scramble removes
+    base = syn.FUZZ_INDEPENDENT_FROM
+    assert syn._fuzz_stream(base - 1) == base - 1 and syn._fuzz_stream(12345) == 12345     # recorded seeds keep their scenes
+    s = [syn._fuzz_stream(base + i) for i in range(2000)]
+    assert len(set(s)) == len(s) and all(0 <= v < 2 ** 64 for v in s)
+    pos = sorted(s)                                                                        # Rng(seed) starts the shared stream at draw number `seed` (mod 2^64)
+    assert min(q - p for p, q in zip(pos, pos[1:])) > 10 ** 6, "two scrambled seeds start within a scene's worth of draws of each other"
+    late = lambda seed: (lambda r: (r[2].X, r[2].Y, r[3]))(syn.fuzz_scene(seed))            # image size and epsilon: drawn late in the stream
+    assert late(base + 7) == late(base + 7)
